@@ -1,0 +1,238 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+TEST INFRASTRUCTURE.  Usage:  python -m oracle.make_golden   (from the repo root)
+
+Every fixture is *data*: seeded inputs, weights (as arrays keyed by the reference's state_dict
+names) and the outputs the reference produced for them.  No reference source text is stored.
+Big configurations (BASELINE cfg2 / cfg3) store only probes / moments / SHA-1 of the fp32 output.
+Weights for every case come from ``oracle.swinir_oracle.random_state_dict`` (deterministic CPU
+generator), loaded into the reference model with ``strict=True`` -- which also pins the
+state_dict schema.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import swinir_oracle as O  # noqa: E402
+from oracle.ref_import import import_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def sha1(a: np.ndarray) -> str:
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sd_to_np(sd):
+    return {"sd." + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def build_ref_model(ns, cfg: O.SwinIRConfig, sd):
+    torch.manual_seed(0)
+    m = ns.SwinIR(drop_path_rate=0.0, **cfg.kwargs())
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m.eval()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ns = import_reference("network_swinir")
+
+    # ---- G1/G2: index maps ------------------------------------------------------------------
+    x = torch.arange(2 * 16 * 24 * 3, dtype=torch.int32).reshape(2, 16, 24, 3)
+    wp = ns.window_partition(x, 8)
+    wr = ns.window_reverse(wp, 8, 16, 24)
+    assert torch.equal(wr, x)
+    big = torch.arange(32 * 64 * 64 * 180, dtype=torch.int32).reshape(32, 64, 64, 180)
+    bigp = ns.window_partition(big, 8)
+    rolled = torch.roll(x, shifts=(-4, -4), dims=(1, 2))
+    rolled_back = torch.roll(x, shifts=(4, 4), dims=(1, 2))
+    rp = ns.window_partition(rolled, 8)
+    save("g1_g2_index_maps", x=x.numpy(), partition=wp.numpy(), roll_m4=rolled.numpy(),
+         roll_p4=rolled_back.numpy(), roll_m4_partition=rp.numpy(),
+         cfg3_partition_sha1=np.array(sha1(bigp.numpy())),
+         cfg3_roll_partition_sha1=np.array(sha1(ns.window_partition(torch.roll(big, (-4, -4), (1, 2)), 8).numpy())))
+    del big, bigp
+
+    # ---- G3: relative position index ----------------------------------------------------------
+    rpis = {}
+    for ws in (7, 8, 16):
+        wa = ns.WindowAttention(12, (ws, ws), 2)
+        rpis[f"rpi_ws{ws}"] = wa.relative_position_index.numpy()
+    assert sha1(rpis["rpi_ws8"]).startswith("8520653ae68ea9ff"), sha1(rpis["rpi_ws8"])
+    save("g3_rpi", **rpis)
+
+    # ---- G4: shift masks ------------------------------------------------------------------------
+    blk = ns.SwinTransformerBlock(12, (64, 64), 2, window_size=8, shift_size=4, mlp_ratio=2)
+    masks = {}
+    for hw in ((64, 64), (48, 48), (16, 24), (24, 40)):
+        m = blk.calculate_mask(hw)
+        vals = set(torch.unique(m).tolist())
+        assert vals <= {0.0, -100.0}
+        masks[f"mask_{hw[0]}x{hw[1]}"] = (m != 0).numpy().astype(np.uint8)
+    assert int(masks["mask_64x64"].reshape(64, -1).any(axis=1).sum()) == 15
+    save("g4_masks", **masks)
+
+    # ---- G5: WindowAttention ------------------------------------------------------------------
+    g = torch.Generator().manual_seed(5)
+    arrays = {}
+    for tag, dim, nH in (("a", 24, 2), ("b", 60, 6)):
+        wa = ns.WindowAttention(dim, (8, 8), nH).eval()
+        with torch.no_grad():
+            for p in wa.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.2 if p.ndim > 1 else 0.1))
+        xw = torch.randn(2 * 4, 64, dim, generator=g)
+        blk = ns.SwinTransformerBlock(dim, (16, 16), nH, window_size=8, shift_size=4, mlp_ratio=2)
+        mask = blk.calculate_mask((16, 16))
+        with torch.no_grad():
+            y0 = wa(xw, None)
+            y1 = wa(xw, mask)
+        arrays.update({f"{tag}.x": xw.numpy(), f"{tag}.y_nomask": y0.numpy(), f"{tag}.y_mask": y1.numpy(),
+                       f"{tag}.nH": np.array(nH)})
+        arrays.update({f"{tag}.sd.{k}": v.numpy() for k, v in wa.state_dict().items()})
+    save("g5_window_attention", **arrays)
+
+    # ---- G6: SwinTransformerBlock ----------------------------------------------------------------
+    arrays = {}
+    for shift in (0, 4):
+        blk = ns.SwinTransformerBlock(24, (16, 16), 2, window_size=8, shift_size=shift, mlp_ratio=2).eval()
+        with torch.no_grad():
+            for n_, p in blk.named_parameters():
+                if "norm" in n_ and n_.endswith("weight"):
+                    p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * (0.2 if p.ndim > 1 else 0.1))
+        xb = torch.randn(2, 256, 24, generator=g)
+        with torch.no_grad():
+            yb = blk(xb, (16, 16))
+            # different x_size than input_resolution -> dynamic mask path (:259-262)
+            xb2 = torch.randn(1, 16 * 24, 24, generator=g)
+            yb2 = blk(xb2, (16, 24))
+        arrays.update({f"s{shift}.x": xb.numpy(), f"s{shift}.y": yb.numpy(),
+                       f"s{shift}.x_16x24": xb2.numpy(), f"s{shift}.y_16x24": yb2.numpy()})
+        arrays.update({f"s{shift}.sd.{k}": v.numpy() for k, v in blk.state_dict().items()})
+    save("g6_swin_block", **arrays)
+
+    # ---- G7: PixelShuffle / Upsample / UpsampleOneStep -----------------------------------------------
+    arrays = {}
+    xi = torch.arange(2 * 36 * 3 * 5, dtype=torch.int32).reshape(2, 36, 3, 5)
+    arrays["ps.x"] = xi.numpy()
+    arrays["ps.r2"] = torch.pixel_shuffle(xi.float(), 2).int().numpy()
+    arrays["ps.r3"] = torch.pixel_shuffle(xi.float(), 3).int().numpy()
+    for scale in (2, 3, 4):
+        up = ns.Upsample(scale, 8).eval()
+        xu = torch.randn(1, 8, 6, 5, generator=g)
+        with torch.no_grad():
+            yu = up(xu)
+        arrays.update({f"up{scale}.x": xu.numpy(), f"up{scale}.y": yu.numpy()})
+        arrays.update({f"up{scale}.sd.{k}": v.numpy() for k, v in up.state_dict().items()})
+    one = ns.UpsampleOneStep(2, 12, 3).eval()
+    xo = torch.randn(2, 12, 6, 5, generator=g)
+    with torch.no_grad():
+        yo = one(xo)
+    arrays.update({"one.x": xo.numpy(), "one.y": yo.numpy()})
+    arrays.update({f"one.sd.{k}": v.numpy() for k, v in one.state_dict().items()})
+    try:
+        ns.Upsample(5, 8)
+        raise AssertionError("scale 5 must raise")
+    except ValueError as e:
+        arrays["up5.error"] = np.array(str(e))
+    save("g7_upsample", **arrays)
+
+    # ---- G8/G9: tiny end-to-end models + one training step ---------------------------------------------
+    tiny = dict(img_size=16, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8,
+                mlp_ratio=2, img_range=1.0, resi_connection="1conv")
+    variants = {
+        "ps4": O.SwinIRConfig(upscale=4, upsampler="pixelshuffle", **tiny),
+        "psd2": O.SwinIRConfig(upscale=2, upsampler="pixelshuffledirect", **tiny),
+        "ps3": O.SwinIRConfig(upscale=3, upsampler="pixelshuffle", **tiny),
+        "nc4": O.SwinIRConfig(upscale=4, upsampler="nearest+conv", **tiny),
+        "dn1": O.SwinIRConfig(upscale=1, upsampler="", **tiny),
+        "ps2_3conv_gray": O.SwinIRConfig(upscale=2, upsampler="pixelshuffle",
+                                         **{**tiny, "in_chans": 1, "resi_connection": "3conv", "embed_dim": 32}),
+    }
+    for tag, cfg in variants.items():
+        sd = O.random_state_dict(cfg, seed=8, scale=3.0)
+        m = build_ref_model(ns, cfg, sd)
+        ref_keys = list(m.state_dict().keys())
+        assert ref_keys == [k for k, _, _ in O.state_dict_schema(cfg)], tag
+        # weights are regenerated from (seed, scale) by the tests; only their digest is stored
+        arrays = {"weight_seed": np.array(8), "weight_scale": np.array(3.0),
+                  "weight_sha1": np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1)
+                                                               for v in sd.values()])))}
+        gi = torch.Generator().manual_seed(80)
+        for hw in ((16, 16), (13, 19), (24, 32)):
+            xin = torch.rand(2, cfg.in_chans, *hw, generator=gi)
+            with torch.no_grad():
+                y = m(xin)
+            arrays[f"x_{hw[0]}x{hw[1]}"] = xin.numpy()
+            arrays[f"y_{hw[0]}x{hw[1]}"] = y.numpy()
+        if tag in ("ps4", "psd2"):
+            # G9: L1 loss, grads, clip 1.0, one AdamW step (finetune_swinir.py:154-176), fp32 CPU
+            mt = build_ref_model(ns, cfg, sd).train()          # drop_path_rate = 0 -> deterministic
+            xin = torch.rand(2, 3, 16, 16, generator=gi)
+            tgt = torch.rand(2, 3, 16 * cfg.upscale, 16 * cfg.upscale, generator=gi)
+            opt = torch.optim.AdamW([p for p in mt.parameters() if p.requires_grad], lr=2e-3, weight_decay=0.01)
+            opt.zero_grad(set_to_none=True)
+            out = mt(xin)
+            loss = torch.nn.functional.l1_loss(out, tgt)
+            loss.backward()
+            arrays["train.x"] = xin.numpy()
+            arrays["train.target"] = tgt.numpy()
+            arrays["train.loss"] = loss.detach().numpy()
+            for n_, p in mt.named_parameters():
+                arrays["grad." + n_] = p.grad.detach().numpy().copy()
+            total = torch.nn.utils.clip_grad_norm_(mt.parameters(), 1.0)
+            arrays["train.grad_norm"] = total.detach().numpy()
+            opt.step()
+            if tag == "psd2":                                   # AdamW result: the small variant is enough
+                for n_, p in mt.named_parameters():
+                    arrays["post." + n_] = p.detach().numpy().copy()
+        save(f"g8_tiny_{tag}", **arrays)
+
+    # ---- G10: BASELINE cfg2 / cfg3 probes ---------------------------------------------------------------------
+    for tag, cfg, bs, hw, wscale in (("cfg2", O.SwinIRConfig.light_x2(), 2, 48, 1.0),
+                                     ("cfg3", O.SwinIRConfig.classical_x4(), 1, 64, 1.5)):
+        sd = O.random_state_dict(cfg, seed=42, scale=wscale)
+        m = build_ref_model(ns, cfg, sd)
+        n_params = sum(p.numel() for p in m.parameters())
+        xin = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(0))
+        with torch.no_grad():
+            y = m(xin)
+        yn = y.numpy()
+        pg = np.random.RandomState(1).randint(0, yn.size, size=64)
+        save(f"g10_{tag}_probe", probe_index=pg, probe_value=yn.reshape(-1)[pg], mean=np.array(yn.mean()),
+             std=np.array(yn.std()), sha1=np.array(sha1(yn)), shape=np.array(yn.shape), n_params=np.array(n_params),
+             n_keys=np.array(len(m.state_dict())), weight_seed=np.array(42), weight_scale=np.array(wscale),
+             input_seed=np.array(0), batch=np.array(bs))
+        print(tag, "params", n_params, "keys", len(m.state_dict()), "mean", yn.mean(), "std", yn.std())
+
+    # ---- G12: PSNR formulas restated from text (finetune_swinir.py:69-74, evaluate.py:24-29) ------------------
+    gp = torch.Generator().manual_seed(12)
+    a = torch.rand(3, 3, 20, 20, generator=gp) * 1.2 - 0.1
+    b = torch.rand(3, 3, 20, 20, generator=gp)
+    pa, pb = a.clamp(0, 1), b.clamp(0, 1)
+    mse = torch.nn.functional.mse_loss(pa, pb, reduction="none").view(3, -1).mean(dim=1)
+    bp = 20.0 * torch.log10(1.0 / torch.sqrt(mse + 1e-8))
+    mse2 = torch.clamp(torch.mean((a - b) ** 2, dim=[1, 2, 3]), min=1e-10)
+    ep = float((20.0 * torch.log10(1.0 / torch.sqrt(mse2))).mean())
+    save("g12_psnr", a=a.numpy(), b=b.numpy(), batch_psnr=bp.numpy(), eval_psnr=np.array(ep))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself (CPU-only)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub_state_dict
+from oracle import swinir_oracle as O
+
+FP32_TOL = 1e-5
+
+
+def _sha1(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_g1_window_partition_reverse_bit_exact():
+    g = load_golden("g1_g2_index_maps")
+    x = g["x"]
+    wp = O.np_window_partition(x, 8)
+    assert wp.dtype == x.dtype and np.array_equal(wp, g["partition"])
+    assert np.array_equal(O.np_window_reverse(wp, 8, 16, 24), x)
+
+
+def test_g1_cfg3_size_partition_sha1():
+    g = load_golden("g1_g2_index_maps")
+    big = np.arange(32 * 64 * 64 * 180, dtype=np.int32).reshape(32, 64, 64, 180)
+    assert _sha1(O.np_window_partition(big, 8)) == str(g["cfg3_partition_sha1"])
+    idx = O.window_token_index(64, 64, 8, 4).reshape(-1)
+    fused = big.reshape(32, 4096, 180)[:, idx].reshape(32 * 64, 8, 8, 180)
+    assert _sha1(fused) == str(g["cfg3_roll_partition_sha1"])
+
+
+def test_g2_roll_bit_exact_and_fused_gather():
+    g = load_golden("g1_g2_index_maps")
+    x = g["x"]
+    assert np.array_equal(O.np_roll2d(x, -4, -4), g["roll_m4"])
+    assert np.array_equal(O.np_roll2d(x, 4, 4), g["roll_p4"])
+    idx = O.window_token_index(16, 24, 8, 4)
+    fused = x.reshape(2, 16 * 24, 3)[:, idx.reshape(-1)].reshape(-1, 8, 8, 3)
+    assert np.array_equal(fused, g["roll_m4_partition"])
+    # the scatter with the same map inverts it (window_reverse + roll(+shift))
+    back = np.empty_like(x.reshape(2, -1, 3))
+    back[:, idx.reshape(-1)] = fused.reshape(2, -1, 3)
+    assert np.array_equal(back.reshape(x.shape), x)
+
+
+@pytest.mark.parametrize("ws", [7, 8, 16])
+def test_g3_relative_position_index(ws):
+    g = load_golden("g3_rpi")
+    rpi = O.relative_position_index(ws)
+    assert rpi.dtype == np.int64 and np.array_equal(rpi, g[f"rpi_ws{ws}"])
+    if ws == 8:
+        assert _sha1(rpi).startswith("8520653ae68ea9ff")
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (48, 48), (16, 24), (24, 40)])
+def test_g4_shift_mask(hw):
+    g = load_golden("g4_masks")
+    m = O.shift_attn_mask(hw[0], hw[1], 8, 4)
+    assert set(np.unique(m).tolist()) <= {0.0, -100.0}
+    assert np.array_equal((m != 0).astype(np.uint8), g[f"mask_{hw[0]}x{hw[1]}"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g5_window_attention(tag):
+    g = load_golden("g5_window_attention")
+    sd = sub_state_dict(g, f"{tag}.sd.")
+    x = torch.from_numpy(g[f"{tag}.x"])
+    nH = int(g[f"{tag}.nH"])
+    y0 = O.window_attention(x, sd, "", nH, 8, None)
+    mask = torch.from_numpy(O.shift_attn_mask(16, 16, 8, 4))
+    y1 = O.window_attention(x, sd, "", nH, 8, mask)
+    assert (y0 - torch.from_numpy(g[f"{tag}.y_nomask"])).abs().max() < FP32_TOL
+    assert (y1 - torch.from_numpy(g[f"{tag}.y_mask"])).abs().max() < FP32_TOL
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+def test_g6_swin_block(shift):
+    g = load_golden("g6_swin_block")
+    sd = sub_state_dict(g, f"s{shift}.sd.")
+    for suffix, hw in (("", (16, 16)), ("_16x24", (16, 24))):
+        x = torch.from_numpy(g[f"s{shift}.x{suffix}"])
+        y = O.swin_block(x, hw, sd, "", 2, 8, shift)
+        assert (y - torch.from_numpy(g[f"s{shift}.y{suffix}"])).abs().max() < FP32_TOL
+
+
+def test_g7_pixel_shuffle_and_upsample():
+    g = load_golden("g7_upsample")
+    x = g["ps.x"]
+    assert np.array_equal(O.np_pixel_shuffle(x, 2), g["ps.r2"])
+    assert np.array_equal(O.np_pixel_shuffle(x, 3), g["ps.r3"])
+    assert torch.equal(O.pixel_shuffle(torch.from_numpy(x), 3), torch.from_numpy(g["ps.r3"]))
+    for scale in (2, 3, 4):
+        sd = sub_state_dict(g, f"up{scale}.sd.")
+        f = torch.from_numpy(g[f"up{scale}.x"])
+        if scale == 3:
+            f = O.pixel_shuffle(torch.nn.functional.conv2d(f, sd["0.weight"], sd["0.bias"], padding=1), 3)
+        else:
+            for i in range(scale // 2):
+                f = O.pixel_shuffle(torch.nn.functional.conv2d(f, sd[f"{2*i}.weight"], sd[f"{2*i}.bias"], padding=1), 2)
+        assert (f - torch.from_numpy(g[f"up{scale}.y"])).abs().max() < FP32_TOL
+    sd = sub_state_dict(g, "one.sd.")
+    f = O.pixel_shuffle(torch.nn.functional.conv2d(torch.from_numpy(g["one.x"]), sd["0.weight"], sd["0.bias"], padding=1), 2)
+    assert (f - torch.from_numpy(g["one.y"])).abs().max() < FP32_TOL
+    assert "scale 5 is not supported" in str(g["up5.error"])
+
+
+TINY = dict(img_size=16, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8,
+            mlp_ratio=2, img_range=1.0, resi_connection="1conv")
+VARIANTS = {
+    "ps4": O.SwinIRConfig(upscale=4, upsampler="pixelshuffle", **TINY),
+    "psd2": O.SwinIRConfig(upscale=2, upsampler="pixelshuffledirect", **TINY),
+    "ps3": O.SwinIRConfig(upscale=3, upsampler="pixelshuffle", **TINY),
+    "nc4": O.SwinIRConfig(upscale=4, upsampler="nearest+conv", **TINY),
+    "dn1": O.SwinIRConfig(upscale=1, upsampler="", **TINY),
+    "ps2_3conv_gray": O.SwinIRConfig(upscale=2, upsampler="pixelshuffle",
+                                     **{**TINY, "in_chans": 1, "resi_connection": "3conv", "embed_dim": 32}),
+}
+
+
+def tiny_weights(tag):
+    g = load_golden(f"g8_tiny_{tag}")
+    cfg = VARIANTS[tag]
+    sd = O.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g["weight_sha1"]), "weight generator drifted from the one the fixtures were made with"
+    return g, cfg, sd
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_g8_tiny_end_to_end(tag):
+    g, cfg, sd = tiny_weights(tag)
+    for hw in ((16, 16), (13, 19), (24, 32)):
+        x = torch.from_numpy(g[f"x_{hw[0]}x{hw[1]}"])
+        with torch.no_grad():
+            y = O.swinir_forward(sd, cfg, x)
+        ref = torch.from_numpy(g[f"y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape == (2, cfg.in_chans, hw[0] * cfg.upscale, hw[1] * cfg.upscale)
+        assert (y - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["ps4", "psd2"])
+def test_g9_train_step(tag):
+    g, cfg, sd = tiny_weights(tag)
+    x = torch.from_numpy(g["train.x"])
+    t = torch.from_numpy(g["train.target"])
+    state = O.TrainState(sd={k: v.clone() for k, v in sd.items()})
+    loss, total, grads = O.train_step(state, cfg, x, t, lr=2e-3, wd=0.01, grad_clip=1.0)
+    assert abs(float(loss) - float(g["train.loss"])) < 1e-6
+    assert abs(float(total) - float(g["train.grad_norm"])) < 1e-4 * float(g["train.grad_norm"])
+    for k, gr in grads.items():
+        ref = torch.from_numpy(g["grad." + k])
+        assert (gr - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max())), k
+    if tag == "psd2":
+        for k in grads:
+            ref = torch.from_numpy(g["post." + k])
+            assert (state.sd[k] - ref).abs().max() < 2e-6, k
+
+
+@pytest.mark.parametrize("tag,cfg,hw", [("cfg2", O.SwinIRConfig.light_x2(), 48), ("cfg3", O.SwinIRConfig.classical_x4(), 64)])
+def test_g10_full_size_probes(tag, cfg, hw):
+    g = load_golden(f"g10_{tag}_probe")
+    sd = O.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    assert len(sd) == int(g["n_keys"])
+    assert sum(v.numel() for k, v in sd.items() if k in set(O.param_keys(cfg))) == int(g["n_params"])
+    x = torch.rand(int(g["batch"]), 3, hw, hw, generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    with torch.no_grad():
+        y = O.swinir_forward(sd, cfg, x).numpy()
+    assert list(y.shape) == list(g["shape"])
+    assert np.abs(y.reshape(-1)[g["probe_index"]] - g["probe_value"]).max() < 2e-5
+    assert abs(float(y.mean()) - float(g["mean"])) < 1e-5 and abs(float(y.std()) - float(g["std"])) < 1e-5
+
+
+def test_g12_psnr_formulas():
+    g = load_golden("g12_psnr")
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    assert (O.batch_psnr(a, b) - torch.from_numpy(g["batch_psnr"])).abs().max() < 1e-4
+    assert abs(O.eval_psnr(a, b) - float(g["eval_psnr"])) < 1e-4
+
+
+def test_unsupported_scale_raises_like_reference():
+    cfg = O.SwinIRConfig(upscale=5, upsampler="pixelshuffle", **TINY)
+    with pytest.raises(ValueError, match="scale 5 is not supported"):
+        O.state_dict_schema(cfg)
