@@ -1,0 +1,176 @@
+/* srk -- super-resolution kernels for AMD MI355X (gfx950): the C ABI of libsrk.so.
+ *
+ * This is the drop-in boundary of the MI355X-native SwinIR path.  The reference
+ * (ViacheslavTimofeev/tpu_superresolution) has no FFI: its boundary is the Python module
+ * modules/network_swinir.py (constructor + forward + state_dict) and the training step in
+ * modules/finetune_swinir.py.  Each entry point below names the reference code it replaces.
+ * The Python side (tpu_superresolution_amd/) binds these with ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE address (tensor.data_ptr()); the caller owns all memory,
+ *     kernels never allocate; `stream` is a hipStream_t (0 = default stream);
+ *   - all work is enqueued asynchronously on `stream`; no entry point synchronises;
+ *   - return value 0 (SRK_OK) or a negative SRK_E_* code; the message of the last error of the
+ *     calling thread is returned by srk_last_error();
+ *   - "bf16" is raw bfloat16 bits (uint16_t); token tensors use channels padded to a multiple of
+ *     64 ("CP"); pad columns are zero.
+ */
+#ifndef SRK_H_
+#define SRK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRK_OK 0
+#define SRK_E_SHAPE (-1)
+#define SRK_E_NULL (-2)
+#define SRK_E_UNSUPPORTED (-3)
+#define SRK_E_LAUNCH (-4)
+#define SRK_E_ALIGN (-5)
+#define SRK_E_STATE (-6)
+
+typedef void* srk_stream_t;
+
+const char* srk_version(void);
+const char* srk_last_error(void);
+
+/* ---- bit-exact index operations (stand-alone; elem_bytes in {2,4,8}) ------------------------- */
+/* window_partition  network_swinir.py:33-45   x [B,H,W,C] -> out [B*nW, ws, ws, C] */
+int srk_window_partition(const void* x, void* out, int B, int H, int W, int C, int ws, int elem_bytes, srk_stream_t stream);
+/* window_reverse    network_swinir.py:48-62   windows [B*nW, ws, ws, C] -> out [B,H,W,C] */
+int srk_window_reverse(const void* windows, void* out, int B, int H, int W, int C, int ws, int elem_bytes, srk_stream_t stream);
+/* torch.roll(x, shifts=(sh,sw), dims=(1,2))  network_swinir.py:249-252, :269-272 */
+int srk_roll2d(const void* x, void* out, int B, int H, int W, int C, int sh, int sw, int elem_bytes, srk_stream_t stream);
+/* nn.PixelShuffle(r) on NCHW   network_swinir.py:585,588,609   x [B,C*r*r,H,W] -> out [B,C,H*r,W*r] */
+int srk_pixel_shuffle(const void* x, void* out, int B, int C, int H, int W, int r, int elem_bytes, srk_stream_t stream);
+/* SwinTransformerBlock.calculate_mask  network_swinir.py:216-237   mask fp32 [nW, ws*ws, ws*ws] in {0,-100} */
+int srk_shift_mask(float* mask, int H, int W, int ws, int shift, srk_stream_t stream);
+/* relative_position_index  network_swinir.py:92-103   out int64 [ws*ws, ws*ws] */
+int srk_relative_position_index(int64_t* out, int ws, srk_stream_t stream);
+
+/* ---- building-block kernels (internal layouts; used by the executor and by the parity tests) -- */
+typedef struct {
+  int H, W;     /* token grid (multiples of 8) */
+  int shift;    /* 0 or 4 (window 8) */
+} srk_win_geom;
+
+/* nn.LayerNorm over C (eps 1e-5)  network_swinir.py:199,205,519-528,725.  x fp32 [rows][CP]; outputs
+ * y_bf16 / y_f32 [rows][CP] (either may be null), mean/rstd fp32 [rows] (may be null).  If geom is
+ * non-null the output is in WINDOW order: row m reads token roll+partition(m) (:249-256). */
+int srk_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32,
+                      float* mean, float* rstd, int rows, int C, int CP, const srk_win_geom* geom, srk_stream_t stream);
+/* softmax(q k^T + rel-pos-bias + shift-mask) v   network_swinir.py:124-142.
+ * qkv bf16 [3][B_][nH][64][32] (q pre-scaled), bias_dense fp32 [nH][64][64], out bf16 [B_*64][nH*32]. */
+int srk_window_attention_fwd(const uint16_t* qkv, const float* bias_dense, uint16_t* out, int64_t B_, int nH,
+                             const srk_win_geom* geom, srk_stream_t stream);
+/* gradient of the above.  d_out bf16 [B_*64][nH*32]; d_qkv bf16 [B_*64][3*nH*32] (columns which,h,d);
+ * d_table fp32 [225][nH] is ACCUMULATED; slab = scratch of srk_window_attention_bwd_scratch() bytes. */
+int srk_window_attention_bwd(const uint16_t* qkv, const float* bias_dense, const uint16_t* d_out, uint16_t* d_qkv,
+                             float* d_table, void* slab, int64_t B_, int nH, float scale, const srk_win_geom* geom,
+                             srk_stream_t stream);
+size_t srk_window_attention_bwd_scratch(int64_t B_, int nH);
+/* dense bias [nH][64][64] from table [225][nH]   network_swinir.py:127-129 */
+int srk_rel_pos_bias_expand(const float* table, float* bias_dense, int nH, srk_stream_t stream);
+/* y[M][N] = a[M][K] . w[N][K]^T + bias  (bf16 in, fp32 accumulate, bf16 out); K % 64 == 0, N % 64 == 0 */
+int srk_linear_bf16(const uint16_t* a, const uint16_t* w, const float* bias, uint16_t* y, int M, int N, int K, srk_stream_t stream);
+/* dw[N][K] += y[M][N]^T . x[M][K] ; db[N] += colsum(y)   (bf16 in, fp32 out, accumulating; db may be null) */
+int srk_linear_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, float* db, int M, int N, int K, srk_stream_t stream);
+/* 3x3/s1/p1 conv on NHWC bf16 [B][H][W][CinP] with packed weights [N][9*CinP] (tap-major), + bias -> bf16 NHWC [..][N] */
+int srk_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y, int B, int H, int W, int CinP, int N,
+                     srk_stream_t stream);
+/* dw[N][9*CinP] += conv weight gradient (y = d output NHWC bf16 [..][N], x = input NHWC bf16 [..][CinP]); db += sum y */
+int srk_conv3x3_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, float* db, int B, int H, int W, int CinP, int N,
+                           srk_stream_t stream);
+int srk_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, srk_stream_t stream);
+/* on-device check of the ds_read_b64_tr_b16 contract the kernels rely on: in u16 [64][16], out u16 [64][8] */
+int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream);
+
+/* ---- training-step pieces  (finetune_swinir.py:148-179) ------------------------------------------ */
+/* F.l1_loss(pred, target) (:66-67, :163) forward + backward in one pass; also counts non-finite pred
+ * values (assert_finite :133-143, :164).  loss (fp32 scalar) and nonfinite (uint32) are ACCUMULATED
+ * (zero them first); d_pred may be null; grad_scale multiplies d_pred (1.0 for a plain backward). */
+int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, float* loss, uint32_t* nonfinite,
+                        int64_t n, float grad_scale, srk_stream_t stream);
+/* sum of squares of a flat fp32 gradient, ACCUMULATED into sumsq[0] (for clip_grad_norm_ :170) */
+int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t stream);
+/* clip_grad_norm_(max_norm) + AdamW step (:168-171, :303) on flat fp32 buffers.  The clip coefficient is
+ * computed on the device from sumsq[0] (no host sync); grads are first divided by grad_div (world size).
+ * max_norm <= 0 disables clipping.  step is the 1-based step count. */
+int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const float* sumsq, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, srk_stream_t stream);
+
+/* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
+enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1, SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2 };
+
+typedef struct {
+  int img_size;          /* constructor img_size // patch_size: only its relation to window_size matters (:193-196) */
+  int in_chans;          /* 1 or 3 */
+  int embed_dim;         /* C, <= 256 */
+  int num_layers;        /* len(depths), <= 16 */
+  int depths[16];
+  int num_heads[16];     /* C / num_heads <= 32 */
+  int window_size;       /* must be 8 */
+  int hidden_dim;        /* int(C * mlp_ratio) */
+  int upscale;
+  int upsampler;         /* SRK_UPSAMPLER_* */
+  float img_range;
+  float mean[3];         /* (0.4488, 0.4371, 0.4040) for 3-channel input, 0 otherwise (:658-662) */
+  float qk_scale;        /* <= 0: head_dim ** -0.5 */
+} srk_swinir_config;
+
+typedef struct srk_swinir_plan srk_swinir_plan;
+
+/* Unsupported configurations return SRK_E_UNSUPPORTED with a message (no CPU fallback exists). */
+int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** plan);
+void srk_swinir_plan_destroy(srk_swinir_plan* plan);
+
+/* Flat parameter buffer: fp32, every tensor in the reference's state_dict layout at a 64-float aligned
+ * offset, in named_parameters() order. */
+int64_t srk_swinir_param_floats(const srk_swinir_plan* plan);
+int srk_swinir_param_count(const srk_swinir_plan* plan);
+/* name: reference state_dict key; shape: up to 4 dims (ndim returned) */
+int srk_swinir_param_info(const srk_swinir_plan* plan, int index, const char** name, int64_t* offset, int64_t* numel,
+                          int* ndim, int64_t shape[4]);
+
+/* Device-resident constant tables the plan needs (pack descriptors): size, then upload into caller memory. */
+size_t srk_swinir_const_bytes(const srk_swinir_plan* plan);
+int srk_swinir_const_init(srk_swinir_plan* plan, void* const_dev, srk_stream_t stream);
+
+/* Packed (padded bf16 + fp32 side tables) weights: refresh after every parameter update. */
+size_t srk_swinir_packed_bytes(const srk_swinir_plan* plan);
+int srk_swinir_pack(srk_swinir_plan* plan, const float* params, void* packed, srk_stream_t stream);
+
+/* Workspace for one forward (+ backward if training != 0) at batch B and (unpadded) input size H0 x W0. */
+size_t srk_swinir_workspace_bytes(const srk_swinir_plan* plan, int B, int H0, int W0, int training);
+
+/* x fp32 NCHW [B][in_chans][H0][W0] in [0,1]  ->  y fp32 NCHW [B][in_chans][H0*s][W0*s].
+ * training != 0 keeps the activations the backward needs in `workspace`.
+ * drop_scale: null, or fp32 [n_blocks][2][B] per-sample DropPath factors (0 or 1/keep) for the
+ * attention and MLP residual branches (timm DropPath in SwinTransformerBlock :276-277). */
+int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* packed, const float* x, float* y,
+                       void* workspace, int B, int H0, int W0, int training, const float* drop_scale, srk_stream_t stream);
+
+/* Backward in segments so the caller can overlap the gradient all-reduce of finished segments:
+ * segment 0 = reconstruction tail + conv_after_body + final norm, 1..L = RSTB L-1..0, L+1 = patch-embed
+ * norm + conv_first.  Segments must be run in increasing order after a training forward with the same
+ * (B,H0,W0,workspace,drop_scale).  d_y fp32 NCHW like y.  grads: flat fp32 like params, ACCUMULATED.
+ * After segment s, grads[begin,end) of srk_swinir_segment_range(s) are final. */
+int srk_swinir_num_segments(const srk_swinir_plan* plan);
+int srk_swinir_segment_range(const srk_swinir_plan* plan, int segment, int64_t* begin, int64_t* end);
+int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* packed, float* grads, const float* d_y,
+                        void* workspace, int B, int H0, int W0, const float* drop_scale, int seg_begin, int seg_end,
+                        srk_stream_t stream);
+
+/* Debug/parity access: byte offset and byte size of a named activation inside `workspace` for the
+ * geometry of the last srk_swinir_workspace_bytes() query; returns SRK_E_STATE if unknown. */
+int srk_swinir_workspace_lookup(const srk_swinir_plan* plan, const char* name, size_t* offset, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRK_H_ */

@@ -1,0 +1,117 @@
+"""ctypes binding of libsrk.so (include/srk.h).  The library is required: there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsrk.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "srk.h")
+
+_lib = None
+
+
+class SrkError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libsrk error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class SrkUnsupported(NotImplementedError):
+    pass
+
+
+class WinGeom(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("shift", C.c_int)]
+
+
+class SwinIRConfig(C.Structure):
+    _fields_ = [("img_size", C.c_int), ("in_chans", C.c_int), ("embed_dim", C.c_int), ("num_layers", C.c_int),
+                ("depths", C.c_int * 16), ("num_heads", C.c_int * 16), ("window_size", C.c_int),
+                ("hidden_dim", C.c_int), ("upscale", C.c_int), ("upsampler", C.c_int), ("img_range", C.c_float),
+                ("mean", C.c_float * 3), ("qk_scale", C.c_float)]
+
+
+UPSAMPLER_PIXELSHUFFLE = 1
+UPSAMPLER_PIXELSHUFFLEDIRECT = 2
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_geom_p = C.POINTER(WinGeom)
+
+_SIGNATURES = {
+    "srk_version": (C.c_char_p, []),
+    "srk_last_error": (C.c_char_p, []),
+    "srk_window_partition": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_window_reverse": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_roll2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_pixel_shuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_shift_mask": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "srk_relative_position_index": (_i, [_vp, _i, _vp]),
+    "srk_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _geom_p, _vp]),
+    "srk_window_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _geom_p, _vp]),
+    "srk_window_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _geom_p, _vp]),
+    "srk_window_attention_bwd_scratch": (_sz, [_i64, _i]),
+    "srk_rel_pos_bias_expand": (_i, [_vp, _vp, _i, _vp]),
+    "srk_linear_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srk_linear_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srk_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "srk_probe_trread": (_i, [_vp, _vp, _vp]),
+    "srk_l1_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
+    "srk_grad_sumsq": (_i, [_vp, _i64, _vp, _vp]),
+    "srk_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    "srk_swinir_plan_create": (_i, [C.POINTER(SwinIRConfig), C.POINTER(_vp)]),
+    "srk_swinir_plan_destroy": (None, [_vp]),
+    "srk_swinir_param_floats": (_i64, [_vp]),
+    "srk_swinir_param_count": (_i, [_vp]),
+    "srk_swinir_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i),
+                                   C.POINTER(_i64 * 4)]),
+    "srk_swinir_const_bytes": (_sz, [_vp]),
+    "srk_swinir_const_init": (_i, [_vp, _vp, _vp]),
+    "srk_swinir_packed_bytes": (_sz, [_vp]),
+    "srk_swinir_pack": (_i, [_vp, _vp, _vp, _vp]),
+    "srk_swinir_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "srk_swinir_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "srk_swinir_num_segments": (_i, [_vp]),
+    "srk_swinir_segment_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "srk_swinir_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "srk_swinir_workspace_lookup": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
+}
+
+
+def declared_symbols() -> List[str]:
+    """Every function name declared in include/srk.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srk_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> C.CDLL:
+    """Load libsrk.so (raises if it has not been built: `python -m tpu_superresolution_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension is required (no fallback path exists); "
+                               "build it with `python -m tpu_superresolution_amd.build`")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == 0:
+        return
+    msg = lib().srk_last_error().decode()
+    if rc == -3:
+        raise SrkUnsupported(msg)
+    if rc == -1 and "is not supported" in msg:
+        raise ValueError(msg)
+    raise SrkError(rc, msg)

@@ -1,0 +1,198 @@
+// extern "C" surface of libsrk.so (include/srk.h): argument validation + error reporting around the
+// kernel launchers.  No torch types, no allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void srk_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int srk_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    srk_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return SRK_E_LAUNCH;
+  }
+  return SRK_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define REQ_PTR(p) SRK_REQUIRE((p) != nullptr, SRK_E_NULL, "%s: null pointer '%s'", __func__, #p)
+#define REQ_ALIGN(p) SRK_REQUIRE(aligned16(p), SRK_E_ALIGN, "%s: '%s' is not 16-byte aligned", __func__, #p)
+
+static int make_geom(const srk_win_geom* g, WinGeom* out, const char* fn) {
+  SRK_REQUIRE(g->H > 0 && g->W > 0 && g->H % 8 == 0 && g->W % 8 == 0, SRK_E_SHAPE, "%s: H,W must be multiples of 8 (got %d,%d)",
+              fn, g->H, g->W);
+  SRK_REQUIRE(g->shift == 0 || g->shift == 4, SRK_E_SHAPE, "%s: shift must be 0 or 4 (got %d)", fn, g->shift);
+  out->H = g->H;
+  out->W = g->W;
+  out->nWw = g->W / 8;
+  out->nW = (g->H / 8) * (g->W / 8);
+  out->shift = g->shift;
+  return SRK_OK;
+}
+
+extern "C" {
+
+const char* srk_version(void) { return "srk 0.1 (gfx950)"; }
+const char* srk_last_error(void) { return g_err; }
+
+int srk_window_partition(const void* x, void* out, int B, int H, int W, int C, int ws, int elem_bytes, srk_stream_t stream) {
+  REQ_PTR(x); REQ_PTR(out);
+  SRK_REQUIRE(B > 0 && C > 0 && ws > 0 && H > 0 && W > 0 && H % ws == 0 && W % ws == 0, SRK_E_SHAPE,
+              "window_partition: H=%d,W=%d must be positive multiples of ws=%d", H, W, ws);
+  return srk_launch_window_partition(x, out, B, H, W, C, ws, elem_bytes, 0, (hipStream_t)stream);
+}
+
+int srk_window_reverse(const void* windows, void* out, int B, int H, int W, int C, int ws, int elem_bytes, srk_stream_t stream) {
+  REQ_PTR(windows); REQ_PTR(out);
+  SRK_REQUIRE(B > 0 && C > 0 && ws > 0 && H > 0 && W > 0 && H % ws == 0 && W % ws == 0, SRK_E_SHAPE,
+              "window_reverse: H=%d,W=%d must be positive multiples of ws=%d", H, W, ws);
+  return srk_launch_window_partition(windows, out, B, H, W, C, ws, elem_bytes, 1, (hipStream_t)stream);
+}
+
+int srk_roll2d(const void* x, void* out, int B, int H, int W, int C, int sh, int sw, int elem_bytes, srk_stream_t stream) {
+  REQ_PTR(x); REQ_PTR(out);
+  SRK_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SRK_E_SHAPE, "roll2d: bad shape");
+  return srk_launch_roll2d(x, out, B, H, W, C, sh, sw, elem_bytes, (hipStream_t)stream);
+}
+
+int srk_pixel_shuffle(const void* x, void* out, int B, int C, int H, int W, int r, int elem_bytes, srk_stream_t stream) {
+  REQ_PTR(x); REQ_PTR(out);
+  SRK_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && r > 0, SRK_E_SHAPE, "pixel_shuffle: bad shape");
+  return srk_launch_pixel_shuffle(x, out, B, C, H, W, r, elem_bytes, (hipStream_t)stream);
+}
+
+int srk_shift_mask(float* mask, int H, int W, int ws, int shift, srk_stream_t stream) {
+  REQ_PTR(mask);
+  SRK_REQUIRE(ws > 0 && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws, SRK_E_SHAPE,
+              "shift_mask: shift_size must in 0-window_size (H=%d W=%d ws=%d shift=%d)", H, W, ws, shift);
+  return srk_launch_shift_mask(mask, H, W, ws, shift, (hipStream_t)stream);
+}
+
+int srk_relative_position_index(int64_t* out, int ws, srk_stream_t stream) {
+  REQ_PTR(out);
+  SRK_REQUIRE(ws > 0 && ws <= 64, SRK_E_SHAPE, "relative_position_index: bad ws %d", ws);
+  return srk_launch_rel_pos_index((long long*)out, ws, (hipStream_t)stream);
+}
+
+int srk_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32, float* mean,
+                      float* rstd, int rows, int C, int CP, const srk_win_geom* geom, srk_stream_t stream) {
+  REQ_PTR(x); REQ_PTR(gamma); REQ_PTR(beta); REQ_ALIGN(x);
+  SRK_REQUIRE(rows > 0, SRK_E_SHAPE, "layernorm: rows=%d", rows);
+  SRK_REQUIRE((mean == nullptr) == (rstd == nullptr), SRK_E_NULL, "layernorm: mean/rstd must both be given or both null");
+  WinGeom g;
+  if (geom) {
+    int rc = make_geom(geom, &g, "layernorm");
+    if (rc) return rc;
+    SRK_REQUIRE(rows % (g.H * g.W) == 0, SRK_E_SHAPE, "layernorm: rows %d not a multiple of H*W", rows);
+  }
+  return srk_launch_ln_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, rows, C, CP, geom ? &g : nullptr, (hipStream_t)stream);
+}
+
+int srk_window_attention_fwd(const uint16_t* qkv, const float* bias_dense, uint16_t* out, int64_t B_, int nH,
+                             const srk_win_geom* geom, srk_stream_t stream) {
+  REQ_PTR(qkv); REQ_PTR(bias_dense); REQ_PTR(out); REQ_PTR(geom); REQ_ALIGN(qkv); REQ_ALIGN(out); REQ_ALIGN(bias_dense);
+  WinGeom g;
+  int rc = make_geom(geom, &g, "window_attention_fwd");
+  if (rc) return rc;
+  SRK_REQUIRE(B_ > 0 && B_ % g.nW == 0 && nH > 0 && nH <= 64, SRK_E_SHAPE, "window_attention_fwd: B_=%lld nW=%d nH=%d",
+              (long long)B_, g.nW, nH);
+  return srk_launch_attn_fwd(qkv, bias_dense, out, B_, nH, g, (hipStream_t)stream);
+}
+
+size_t srk_window_attention_bwd_scratch(int64_t B_, int nH) {
+  return (size_t)srk_attn_bwd_slabs(B_, nullptr) * nH * 4096 * sizeof(float);
+}
+
+int srk_window_attention_bwd(const uint16_t* qkv, const float* bias_dense, const uint16_t* d_out, uint16_t* d_qkv,
+                             float* d_table, void* slab, int64_t B_, int nH, float scale, const srk_win_geom* geom,
+                             srk_stream_t stream) {
+  REQ_PTR(qkv); REQ_PTR(bias_dense); REQ_PTR(d_out); REQ_PTR(d_qkv); REQ_PTR(d_table); REQ_PTR(slab); REQ_PTR(geom);
+  REQ_ALIGN(qkv); REQ_ALIGN(d_out); REQ_ALIGN(d_qkv); REQ_ALIGN(slab);
+  WinGeom g;
+  int rc = make_geom(geom, &g, "window_attention_bwd");
+  if (rc) return rc;
+  SRK_REQUIRE(B_ > 0 && B_ % g.nW == 0 && nH > 0 && nH <= 64, SRK_E_SHAPE, "window_attention_bwd: B_=%lld nW=%d nH=%d",
+              (long long)B_, g.nW, nH);
+  return srk_launch_attn_bwd(qkv, bias_dense, d_out, d_qkv, (float*)slab, d_table, B_, nH, g, scale, (hipStream_t)stream);
+}
+
+int srk_rel_pos_bias_expand(const float* table, float* bias_dense, int nH, srk_stream_t stream) {
+  REQ_PTR(table); REQ_PTR(bias_dense);
+  return srk_launch_rpb_expand(table, bias_dense, nH, (hipStream_t)stream);
+}
+
+int srk_linear_bf16(const uint16_t* a, const uint16_t* w, const float* bias, uint16_t* y, int M, int N, int K, srk_stream_t stream) {
+  REQ_PTR(a); REQ_PTR(w); REQ_PTR(y); REQ_ALIGN(a); REQ_ALIGN(w); REQ_ALIGN(y);
+  GemmParams p = {};
+  p.A = a; p.lda = K; p.Wt = w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.outb = y; p.ldo = N;
+  return srk_launch_gemm(LD_ROWS, EP_BF16, p, (hipStream_t)stream);
+}
+
+int srk_linear_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, float* db, int M, int N, int K, srk_stream_t stream) {
+  REQ_PTR(y); REQ_PTR(x); REQ_PTR(dw); REQ_ALIGN(y); REQ_ALIGN(x);
+  WgradParams p = {};
+  p.Y = y; p.ldy = N; p.X = x; p.ldx = K; p.M = M; p.N = N; p.K = K; p.dW = dw; p.ldw = K; p.db = db;
+  return srk_launch_wgrad(p, (hipStream_t)stream);
+}
+
+int srk_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y, int B, int H, int W, int CinP, int N,
+                     srk_stream_t stream) {
+  REQ_PTR(x); REQ_PTR(w); REQ_PTR(y); REQ_ALIGN(x); REQ_ALIGN(w); REQ_ALIGN(y);
+  GemmParams p = {};
+  p.A = x; p.Wt = w; p.M = B * H * W; p.N = N; p.K = 9 * CinP; p.B = B; p.H = H; p.W = W; p.CinP = CinP;
+  p.bias = bias; p.outb = y; p.ldo = N;
+  return srk_launch_gemm(LD_CONV3, EP_BF16, p, (hipStream_t)stream);
+}
+
+int srk_conv3x3_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, float* db, int B, int H, int W, int CinP, int N,
+                           srk_stream_t stream) {
+  REQ_PTR(y); REQ_PTR(x); REQ_PTR(dw); REQ_ALIGN(y); REQ_ALIGN(x);
+  WgradParams p = {};
+  p.Y = y; p.ldy = N; p.X = x; p.ldx = CinP; p.M = B * H * W; p.N = N; p.K = CinP; p.dW = dw; p.ldw = 9 * CinP; p.db = db;
+  p.conv = 1; p.B = B; p.H = H; p.W = W; p.r = 1;
+  return srk_launch_wgrad(p, (hipStream_t)stream);
+}
+
+int srk_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, srk_stream_t stream) {
+  REQ_PTR(x); REQ_PTR(y);
+  return srk_launch_cast_f32_bf16(x, y, n, (hipStream_t)stream);
+}
+
+int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream) {
+  REQ_PTR(in); REQ_PTR(out);
+  return srk_launch_probe_trread(in, out, (hipStream_t)stream);
+}
+
+int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, float* loss, uint32_t* nonfinite, int64_t n,
+                        float grad_scale, srk_stream_t stream) {
+  REQ_PTR(pred); REQ_PTR(target); REQ_PTR(loss); REQ_PTR(nonfinite);
+  SRK_REQUIRE(n > 0, SRK_E_SHAPE, "l1_loss: n=%lld", (long long)n);
+  return srk_launch_l1_loss(pred, target, d_pred, loss, nonfinite, n, grad_scale, (hipStream_t)stream);
+}
+
+int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t stream) {
+  REQ_PTR(grads); REQ_PTR(sumsq);
+  return srk_launch_sumsq(grads, n, sumsq, (hipStream_t)stream);
+}
+
+int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sumsq,
+                        float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, srk_stream_t stream) {
+  REQ_PTR(params); REQ_PTR(grads); REQ_PTR(exp_avg); REQ_PTR(exp_avg_sq);
+  SRK_REQUIRE(max_norm <= 0.f || sumsq != nullptr, SRK_E_NULL, "adamw: clipping needs sumsq");
+  SRK_REQUIRE(step >= 1 && grad_div > 0.f, SRK_E_SHAPE, "adamw: step=%d grad_div=%f", step, grad_div);
+  return srk_launch_adamw(params, grads, exp_avg, exp_avg_sq, n, sumsq, max_norm, grad_div, lr, beta1, beta2, eps,
+                          weight_decay, step, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// (Shifted-)window multi-head attention, forward and backward, for 8x8 windows (N = 64 tokens)
+// and head_dim padded to 32.  Reference: WindowAttention.forward network_swinir.py:114-145 (the
+// q/k/v projections and the output projection are separate GEMMs; this file is
+// softmax(q k^T + bias + mask) v and its gradient).
+//
+// One wave owns one (window, head) pair at a time and walks `wpw` consecutive windows of the same
+// head, keeping that head's dense relative-position bias (64x64 fp32, 64 VGPRs) in registers.
+// All matrix products are v_mfma_f32_16x16x32_bf16.  The scores are computed transposed
+// (S^T[j][i] = k_j . q_i) so that a softmax row (fixed query i, all keys j) lives in 16 registers
+// of 4 lanes: the row max / row sum need two cross-lane steps (xor 16, xor 32), and the normalised
+// probabilities are already in MFMA B-operand form (k = key index) for the P.V product.
+// Operands that are needed "transposed" (V^T, Q^T, K^T, dO^T, P, dS) are read from small
+// wave-private LDS tiles with ds_read_b64_tr_b16.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 40;   // LDS row stride (elements) of a [64][32] bf16 tile (80 B: 16-B aligned rows)
+constexpr int PS = 72;   // LDS row stride of the [64][64] bf16 P / dS tile (144 B)
+
+__device__ __forceinline__ void stage_tile_64x32(bf16_t* dst, const bf16_t* src, long long row_stride, int lane) {
+  // 64 rows x 64 B; lane handles 4 x 16 B
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = lane + 64 * t;
+    const int row = idx >> 2, ch = idx & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + row * row_stride + ch * 8);
+    *reinterpret_cast<uint4*>(dst + row * TS + ch * 8) = v;
+  }
+}
+
+__device__ __forceinline__ bf16x8_t cat4(bf16x4_t lo, bf16x4_t hi) {
+  return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// transposed fragment: lane (r16, g) gets T[k = k0 + 8g + jj][col c0 + r16], jj = 0..7 (natural k order)
+__device__ __forceinline__ bf16x8_t tr_frag_nat(const bf16_t* tile, int stride, int k0, int c0, int lane) {
+  const int g = lane >> 4;
+  return cat4(lds_tr_read(tr_addr(tile, stride, k0 + 8 * g, c0, lane)),
+              lds_tr_read(tr_addr(tile, stride, k0 + 8 * g + 4, c0, lane)));
+}
+
+// transposed fragment in "accumulator k order": jj<4 -> k = k0 + 4g + jj ; jj>=4 -> k = k0 + 16 + 4g + (jj-4)
+__device__ __forceinline__ bf16x8_t tr_frag_acc(const bf16_t* tile, int stride, int k0, int c0, int lane) {
+  const int g = lane >> 4;
+  return cat4(lds_tr_read(tr_addr(tile, stride, k0 + 4 * g, c0, lane)),
+              lds_tr_read(tr_addr(tile, stride, k0 + 16 + 4 * g, c0, lane)));
+}
+
+__device__ __forceinline__ bf16x8_t row_frag(const bf16_t* tile, int stride, int row, int k0) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * stride + k0);
+}
+
+__device__ __forceinline__ float xmax4(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xsum4(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// scores^T + bias + mask -> probabilities^T (in place), T-layout: s[jt][it][e] = S[i=16it+r16][j=16jt+4g+e]
+__device__ __forceinline__ void softmax_T(f32x4_t (&s)[4][4], const f32x4_t (&bias)[4][4], const WinGeom& geom,
+                                          int w, int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wy = w / geom.nWw, wx = w - wy * geom.nWw;
+  const bool masked = geom.shift > 0 && (wy == geom.H / 8 - 1 || wx == geom.nWw - 1);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) s[jt][it] += bias[jt][it];
+  if (masked) {
+    int labi[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) labi[it] = win_region_label(geom, w, 16 * it + r16);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int labj = win_region_label(geom, w, 16 * jt + 4 * g + e);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (labj != labi[it]) s[jt][it][e] += -100.0f;   // network_swinir.py:235 (-100, not -inf)
+      }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][it][e]);
+    mx = xmax4(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = __expf(s[jt][it][e] - mx);
+        s[jt][it][e] = pv;
+        sum += pv;
+      }
+    sum = xsum4(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[jt][it][e] *= inv;
+  }
+}
+
+__device__ __forceinline__ void load_bias_T(f32x4_t (&bias)[4][4], const float* biasd, int h, int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float4 b = *reinterpret_cast<const float4*>(biasd + ((h * 64) + 16 * it + r16) * 64 + 16 * jt + 4 * g);
+      bias[jt][it] = f32x4_t{b.x, b.y, b.z, b.w};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
+                                                       bf16_t* __restrict__ ao, long long B_, int nH, int CA,
+                                                       WinGeom geom, int wpw) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[4][64 * TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y;
+  bf16_t* Vs = lds[wave];
+  const long long w_begin = ((long long)blockIdx.x * 4 + wave) * wpw;
+
+  f32x4_t bias[4][4];
+  load_bias_T(bias, biasd, h, lane);
+
+  for (int wi = 0; wi < wpw; ++wi) {
+    const long long b_ = w_begin + wi;
+    if (b_ >= B_) break;
+    const bf16_t* Q = qkv + ((0 * B_ + b_) * nH + h) * 2048;
+    const bf16_t* K = qkv + ((1 * B_ + b_) * nH + h) * 2048;
+    const bf16_t* V = qkv + ((2 * B_ + b_) * nH + h) * 2048;
+    stage_tile_64x32(Vs, V, 32, lane);
+
+    bf16x8_t kf[4], qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      kf[t] = *reinterpret_cast<const bf16x8_t*>(K + (16 * t + r16) * 32 + 8 * g);
+      qf[t] = *reinterpret_cast<const bf16x8_t*>(Q + (16 * t + r16) * 32 + 8 * g);
+    }
+    f32x4_t s[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        s[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+
+    softmax_T(s, bias, geom, (int)(b_ % geom.nW), lane);
+
+    __builtin_amdgcn_wave_barrier();
+    f32x4_t o[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) o[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      bf16x8_t vf[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) vf[dt] = tr_frag_acc(Vs, TS, 32 * ss, 16 * dt, lane);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const uint2 lo = pack_bf4(s[2 * ss][it][0], s[2 * ss][it][1], s[2 * ss][it][2], s[2 * ss][it][3]);
+        const uint2 hi = pack_bf4(s[2 * ss + 1][it][0], s[2 * ss + 1][it][1], s[2 * ss + 1][it][2], s[2 * ss + 1][it][3]);
+        const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[dt][it], 0, 0, 0);
+      }
+    }
+    // o[dt][it][e] = O[i = 16it + r16][d = 16dt + 4g + e]
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16_t* dst = ao + (b_ * 64 + 16 * it + r16) * CA + h * 32 + 16 * dt + 4 * g;
+        *reinterpret_cast<uint2*>(dst) = pack_bf4(o[dt][it][0], o[dt][it][1], o[dt][it][2], o[dt][it][3]);
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
+                                                       const bf16_t* __restrict__ dao, bf16_t* __restrict__ dqkv,
+                                                       float* __restrict__ dbias_slab, long long B_, int nH, int CA,
+                                                       WinGeom geom, int wpw, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int PER_WAVE = 4 * 64 * TS + 64 * PS;  // elements
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw) + wave * PER_WAVE;
+  bf16_t* Ks = Qs + 64 * TS;
+  bf16_t* Vs = Ks + 64 * TS;
+  bf16_t* Os = Vs + 64 * TS;   // dO
+  bf16_t* Pb = Os + 64 * TS;   // P, then dS, as [i][j]
+  const long long slab_id = (long long)blockIdx.x * 4 + wave;
+  const long long w_begin = slab_id * wpw;
+  const int ldq = 3 * CA;
+
+  f32x4_t bias[4][4], dbias[4][4];
+  load_bias_T(bias, biasd, h, lane);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) dbias[jt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int wi = 0; wi < wpw; ++wi) {
+    const long long b_ = w_begin + wi;
+    if (b_ >= B_) break;
+    stage_tile_64x32(Qs, qkv + ((0 * B_ + b_) * nH + h) * 2048, 32, lane);
+    stage_tile_64x32(Ks, qkv + ((1 * B_ + b_) * nH + h) * 2048, 32, lane);
+    stage_tile_64x32(Vs, qkv + ((2 * B_ + b_) * nH + h) * 2048, 32, lane);
+    stage_tile_64x32(Os, dao + (b_ * 64) * CA + h * 32, CA, lane);
+    __builtin_amdgcn_wave_barrier();
+
+    // S^T and dP^T (both [j][i], sum over d)
+    f32x4_t s[4][4], dp[4][4];
+    {
+      bf16x8_t kf[4], qf[4], vf[4], of[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        kf[t] = row_frag(Ks, TS, 16 * t + r16, 8 * g);
+        qf[t] = row_frag(Qs, TS, 16 * t + r16, 8 * g);
+        vf[t] = row_frag(Vs, TS, 16 * t + r16, 8 * g);
+        of[t] = row_frag(Os, TS, 16 * t + r16, 8 * g);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          s[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          dp[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt], of[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+    softmax_T(s, bias, geom, (int)(b_ % geom.nW), lane);
+
+    // P -> LDS as [i][j] (bf16), then dS = P o (dP - rowsum(P o dP))
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float dl = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        *reinterpret_cast<uint2*>(Pb + (16 * it + r16) * PS + 16 * jt + 4 * g) =
+            pack_bf4(s[jt][it][0], s[jt][it][1], s[jt][it][2], s[jt][it][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dl += s[jt][it][e] * dp[jt][it][e];
+      }
+      dl = xsum4(dl);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ds = s[jt][it][e] * (dp[jt][it][e] - dl);
+          dp[jt][it][e] = ds;
+          dbias[jt][it][e] += ds;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // dV^T[d][j] = sum_i dO^T[d][i] P[i][j]
+    {
+      f32x4_t acc[2][4];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[dt][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        bf16x8_t af[2], bfr[4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) af[dt] = tr_frag_nat(Os, TS, 32 * ss, 16 * dt, lane);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) bfr[jt] = tr_frag_nat(Pb, PS, 32 * ss, 16 * jt, lane);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+            acc[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[jt], acc[dt][jt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16_t* dst = dqkv + (b_ * 64 + 16 * jt + r16) * ldq + 2 * CA + h * 32 + 16 * dt + 4 * g;
+          *reinterpret_cast<uint2*>(dst) = pack_bf4(acc[dt][jt][0], acc[dt][jt][1], acc[dt][jt][2], acc[dt][jt][3]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dS -> LDS as [i][j]
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+        *reinterpret_cast<uint2*>(Pb + (16 * it + r16) * PS + 16 * jt + 4 * g) =
+            pack_bf4(dp[jt][it][0], dp[jt][it][1], dp[jt][it][2], dp[jt][it][3]);
+    __builtin_amdgcn_wave_barrier();
+
+    // dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]        (Q is already scaled)
+    {
+      f32x4_t acc[2][4];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[dt][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        bf16x8_t af[2], bfr[4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) af[dt] = tr_frag_nat(Qs, TS, 32 * ss, 16 * dt, lane);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) bfr[jt] = tr_frag_nat(Pb, PS, 32 * ss, 16 * jt, lane);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+            acc[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[jt], acc[dt][jt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16_t* dst = dqkv + (b_ * 64 + 16 * jt + r16) * ldq + 1 * CA + h * 32 + 16 * dt + 4 * g;
+          *reinterpret_cast<uint2*>(dst) = pack_bf4(acc[dt][jt][0], acc[dt][jt][1], acc[dt][jt][2], acc[dt][jt][3]);
+        }
+    }
+    // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i]
+    {
+      f32x4_t acc[2][4];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        bf16x8_t af[2], bfr[4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) af[dt] = tr_frag_nat(Ks, TS, 32 * ss, 16 * dt, lane);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) bfr[it] = row_frag(Pb, PS, 16 * it + r16, 32 * ss + 8 * g);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[it], acc[dt][it], 0, 0, 0);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16_t* dst = dqkv + (b_ * 64 + 16 * it + r16) * ldq + 0 * CA + h * 32 + 16 * dt + 4 * g;
+          *reinterpret_cast<uint2*>(dst) =
+              pack_bf4(acc[dt][it][0] * scale, acc[dt][it][1] * scale, acc[dt][it][2] * scale, acc[dt][it][3] * scale);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // per-wave partial d(bias) slab, dense [i][j]
+  float* slab = dbias_slab + ((slab_id * nH + h) * 64) * 64;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      *reinterpret_cast<float4*>(slab + (16 * it + r16) * 64 + 16 * jt + 4 * g) =
+          make_float4(dbias[jt][it][0], dbias[jt][it][1], dbias[jt][it][2], dbias[jt][it][3]);
+}
+
+// d(table)[t][h] += sum over slabs and over (i,j) with rpi(i,j) == t.  One workgroup per (t, h).
+__global__ __launch_bounds__(64) void rpb_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dtable,
+                                                        int nslab, int nH) {
+  const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  // rpi(p,q) = (yp-yq+7)*15 + (xp-xq+7)  ->  dy = t/15 - 7, dx = t%15 - 7
+  const int dy = t / 15 - 7, dx = t % 15 - 7;
+  const int yi = lane >> 3, xi = lane & 7;      // lane = query token i
+  const int yj = yi - dy, xj = xi - dx;
+  float acc = 0.f;
+  if ((unsigned)yj < 8u && (unsigned)xj < 8u) {
+    const int j = yj * 8 + xj;
+    for (int sidx = 0; sidx < nslab; ++sidx) acc += slab[(((long long)sidx * nH + h) * 64 + lane) * 64 + j];
+  }
+  acc = wave_sum64(acc);
+  if (lane == 0) dtable[t * nH + h] += acc;
+}
+
+// dense bias[h][i][j] = table[rpi(i,j)][h]   (network_swinir.py:127-129)
+__global__ void rpb_expand_kernel(const float* __restrict__ table, float* __restrict__ biasd, int nH) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nH * 4096) return;
+  const int h = idx >> 12, i = (idx >> 6) & 63, j = idx & 63;
+  const int t = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+  biasd[idx] = table[t * nH + h];
+}
+
+}  // namespace
+
+int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long long B_, int nH, WinGeom geom,
+                        hipStream_t stream) {
+  const int wpw = B_ >= 4096 ? 4 : 1;
+  dim3 grid((unsigned)((B_ + 4 * wpw - 1) / (4 * wpw)), nH);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, qkv, biasd, ao, B_, nH, nH * 32, geom, wpw);
+  return srk_check_launch("attn_fwd");
+}
+
+int srk_attn_bwd_slabs(long long B_, int* wpw_out) {
+  const int wpw = B_ >= 1024 ? 8 : 1;
+  if (wpw_out) *wpw_out = wpw;
+  const long long blocks = (B_ + 4 * wpw - 1) / (4 * wpw);
+  return (int)(blocks * 4);
+}
+
+int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,
+                        float* dtable, long long B_, int nH, WinGeom geom, float scale, hipStream_t stream) {
+  int wpw;
+  const int nslab = srk_attn_bwd_slabs(B_, &wpw);
+  constexpr size_t lds = (size_t)4 * (4 * 64 * TS + 64 * PS) * sizeof(bf16_t);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      srk_set_error("attn_bwd: cannot reserve %zu bytes of LDS", lds);
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  dim3 grid(nslab / 4, nH);
+  hipLaunchKernelGGL(attn_bwd_kernel, grid, dim3(256), lds, stream, qkv, biasd, dao, dqkv, dbias_slab, B_, nH, nH * 32,
+                     geom, wpw, scale);
+  int rc = srk_check_launch("attn_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(rpb_reduce_kernel, dim3(225, nH), dim3(64), 0, stream, dbias_slab, dtable, nslab, nH);
+  return srk_check_launch("rpb_reduce");
+}
+
+int srk_launch_rpb_expand(const float* table, float* biasd, int nH, hipStream_t stream) {
+  hipLaunchKernelGGL(rpb_expand_kernel, dim3(cdiv(nH * 4096, 256)), dim3(256), 0, stream, table, biasd, nH);
+  return srk_check_launch("rpb_expand");
+}

@@ -1,0 +1,128 @@
+// Shared device/host helpers for the srk (super-resolution kernels) library.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srk.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // MFMA 16x16 C/D fragment
+
+#define SRK_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void srk_set_error(const char* fmt, ...);
+int srk_check_launch(const char* what);
+
+#define SRK_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      srk_set_error(__VA_ARGS__);         \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// bf16 helpers (device)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ uint2 pack_bf4(float a, float b, float c, float d) {
+  return make_uint2(pack_bf2(a, b), pack_bf2(c, d));
+}
+
+__device__ __forceinline__ void unpack_bf2(unsigned u, float& lo, float& hi) {
+  lo = __uint_as_float(u << 16);
+  hi = __uint_as_float(u & 0xffff0000u);
+}
+
+// exact (erf) GELU and its derivative -- nn.GELU default (network_swinir.py:15, Mlp act_layer)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// window index map: window-order row -> raster token (roll(-shift) + window_partition fused;
+// reference network_swinir.py:249-256 and, as the scatter, :265-272).  ws == 8.
+// ---------------------------------------------------------------------------------------------
+struct WinGeom {
+  int H, W;        // feature-map size (multiples of 8)
+  int nWw, nW;     // windows per row, windows per image
+  int shift;       // 0 or 4
+};
+
+__device__ __forceinline__ int win_row_to_token(const WinGeom& g, int m) {
+  const int b_ = m >> 6, p = m & 63;
+  const int b = b_ / g.nW, w = b_ - b * g.nW;
+  const int wy = w / g.nWw, wx = w - wy * g.nWw;
+  int y = wy * 8 + (p >> 3) + g.shift;
+  int x = wx * 8 + (p & 7) + g.shift;
+  if (y >= g.H) y -= g.H;
+  if (x >= g.W) x -= g.W;
+  return (b * g.H + y) * g.W + x;
+}
+
+// region label (0..8) of token p of window w in the shifted frame (network_swinir.py:219-230), ws 8 shift 4
+__device__ __forceinline__ int win_region_label(const WinGeom& g, int w, int p) {
+  const int wy = w / g.nWw, wx = w - wy * g.nWw;
+  const int y = wy * 8 + (p >> 3), x = wx * 8 + (p & 7);
+  const int ly = y < g.H - 8 ? 0 : (y < g.H - 4 ? 1 : 2);
+  const int lx = x < g.W - 8 ? 0 : (x < g.W - 4 ? 1 : 2);
+  return ly * 3 + lx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS helpers
+// ---------------------------------------------------------------------------------------------
+// [rows][64] bf16 tile, 128-B rows, 16-B chunk index XOR-swizzled with (row & 7): conflict-free
+// ds_read_b128 fragment reads (16 rows x one chunk per 16-lane group).
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
+
+// hardware transposed read: per 16-lane group, a 4-row x 16-col block of 16-bit elements is
+// delivered column-major (lane i gets column i of the 4 rows).  Lane 4q+p supplies the address
+// of row q, columns 4p..4p+3.  See srk_probe_trread for the on-device check of this contract.
+__device__ __forceinline__ bf16x4_t lds_tr_read(const bf16_t* p) {
+  typedef __attribute__((ext_vector_type(4))) short s4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(p));
+}
+
+// address helper for lds_tr_read: tile is row-major with `stride` elements per row; the calling
+// lane wants, for its 16-lane group, rows rbase..rbase+3 and columns c0..c0+15.
+__device__ __forceinline__ const bf16_t* tr_addr(const bf16_t* tile, int stride, int rbase, int c0, int lane) {
+  const int ll = lane & 15;
+  return tile + (rbase + (ll >> 2)) * stride + c0 + ((ll & 3) << 2);
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {  // reduce across the 16 lanes sharing lane>>4
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+  v = wave_sum16(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

@@ -1,0 +1,58 @@
+// Internal interface of the MFMA GEMM / implicit-GEMM conv kernel family (gemm.hip).
+#pragma once
+#include "common.h"
+
+// A-operand loaders
+enum SrkLoader {
+  LD_ROWS = 0,     // A[M][lda] bf16 row-major, K contiguous
+  LD_CONV3 = 1,    // 3x3/pad1/stride1 im2col over NHWC bf16 [B][H][W][CinP]; K = 9*CinP (tap-major)
+  LD_CONV3_PS = 2, // same, but the NHWC source is stored pixel-shuffled: logical channel
+                   // n' = (i*r+j)*Cs + c of pixel (y,x) lives at src[b][r*y+i][r*x+j][c]  (dgrad of conv+PixelShuffle)
+};
+
+// epilogues.  v = acc + bias[n] unless noted.
+enum SrkEpilogue {
+  EP_BF16 = 0,       // outb[m*ldo+n] = bf16(v)
+  EP_QKV = 1,        // n=(which,h,d): qkv[which][b_][h][p][d] = bf16(v * (which==0 ? scale : 1))
+  EP_PROJ_RES = 2,   // t=token(m): outf[t][n] = res[t][n] + v     (window_reverse + roll(+shift) + residual)
+  EP_GELU = 3,       // outb[m][n] = bf16(v) (pre-activation u), outb2[m][n] = bf16(gelu(v))
+  EP_RES = 4,        // outf[m][n] = res[m][n] + v ; optional outb[m][n] = bf16(same)
+  EP_DGELU = 5,      // outb[m][n] = bf16(v * gelu'(aux[m][n]))          (no bias)
+  EP_LRELU = 6,      // outb = bf16(leaky_relu(v, slope))
+  EP_PS = 7,         // pixel-shuffle store: n'=(ij)*Cs+c -> outb[b][r*y+i][r*x+j][c] = bf16(v)
+  EP_IMG = 8,        // outf NCHW image: out[b][n][y][x] = v/range + mean[n]  (n < Cimg, crop to Hc x Wc)
+  EP_PS_IMG = 9,     // n=c*r*r+i*r+j: out[b][c][r*y+i][r*x+j] = v/range + mean[c]  (crop)
+  EP_RES_BF16 = 10,  // outb[m][n] = bf16(res[m][n] + v)
+  EP_DLRELU = 11,    // outb = bf16(v * (aux[m][n] > 0 ? 1 : slope))     (no bias)
+  EP_F32_BF16 = 12,  // outf[m][n] = v ; outb[m][n] = bf16(v)             (no bias unless given)
+};
+
+struct GemmParams {
+  // operands
+  const bf16_t* A;     // LD_ROWS: [M][lda];  conv: NHWC source
+  int lda;
+  const bf16_t* Wt;    // packed weights [N][K] bf16 (K contiguous)
+  int M, N, K;
+  // conv geometry (output pixel grid == logical input grid)
+  int B, H, W, CinP;   // CinP: logical input channels per tap (multiple of 64)
+  int r, Cs;           // LD_CONV3_PS / EP_PS / EP_PS_IMG: shuffle factor and stored channel count
+  // epilogue
+  const float* bias;   // [N] fp32 or null
+  float* outf;
+  bf16_t* outb;
+  bf16_t* outb2;
+  const float* res;    // fp32 residual
+  const bf16_t* aux;   // bf16 auxiliary (pre-activation / activation sign)
+  int ldo;             // row stride (elements) of outf/outb/res/aux
+  float scale;         // EP_QKV q scale; EP_LRELU/EP_DLRELU slope
+  int nH, CA;          // EP_QKV: heads and nH*32
+  WinGeom geom;        // EP_PROJ_RES
+  float inv_range;     // EP_IMG / EP_PS_IMG
+  float mean[4];
+  int Cimg, Hc, Wc;    // valid image channels and crop size (output pixels)
+  long long B_;        // EP_QKV: number of windows
+  const float* rowscale;  // per-sample DropPath factor (EP_PROJ_RES / EP_RES: scales v; EP_F32_BF16: scales the bf16 copy)
+  int rows_per_sample;    // tokens per sample for rowscale indexing
+};
+
+int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t stream);

@@ -1,0 +1,38 @@
+// Internal launcher prototypes shared by api.hip and swinir.hip.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+#include "pack.h"
+#include "wgrad.h"
+
+int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long long B_, int nH, WinGeom geom, hipStream_t stream);
+int srk_attn_bwd_slabs(long long B_, int* wpw_out);
+int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,
+                        float* dtable, long long B_, int nH, WinGeom geom, float scale, hipStream_t stream);
+int srk_launch_rpb_expand(const float* table, float* biasd, int nH, hipStream_t stream);
+
+int srk_launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* yb, float* yf, float* mean,
+                      float* rstd, int rows, int C, int CP, const WinGeom* geom, hipStream_t stream);
+int srk_launch_ln_bwd(const bf16_t* dyb, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      float* gx, bf16_t* gxb, float* dgamma, float* dbeta, int rows, int C, int CP, const WinGeom* geom,
+                      int dy_by_m, int stats_by_m, int out_by_m, int accumulate, const float* rowscale, int rows_per_sample,
+                      hipStream_t stream);
+
+int srk_launch_window_partition(const void* x, void* out, int B, int H, int W, int C, int ws, int elem_bytes, int reverse, hipStream_t stream);
+int srk_launch_roll2d(const void* x, void* out, int B, int H, int W, int C, int sh, int sw, int elem_bytes, hipStream_t stream);
+int srk_launch_pixel_shuffle(const void* x, void* out, int B, int C, int H, int W, int r, int elem_bytes, hipStream_t stream);
+int srk_launch_shift_mask(float* mask, int H, int W, int ws, int shift, hipStream_t stream);
+int srk_launch_rel_pos_index(long long* out, int ws, hipStream_t stream);
+int srk_launch_img_prep(const float* x, float* out, int B, int Cimg, int H0, int W0, int H, int W, float range, const float* mean, hipStream_t stream);
+int srk_launch_stem_conv(const float* in, const float* wgt, const float* bias, float* out, int B, int H, int W, int Cin, int C, int CP, hipStream_t stream);
+int srk_launch_stem_wgrad(const float* in, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int C, int CP, hipStream_t stream);
+int srk_launch_img_grad_prep(const float* dpred, float* gy, int B, int Cimg, int Hc, int Wc, int H, int W, int r, int CoP, float inv_range, hipStream_t stream);
+int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP, int Co, int CoP, hipStream_t stream);
+int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP, int Co, int CoP, hipStream_t stream);
+int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream);
+int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStream_t stream);
+int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream);
+int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, float* loss_sum, unsigned* nonfinite, long long n, float grad_scale, hipStream_t stream);
+int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream);
+int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t stream);
+int srk_launch_probe_trread(const bf16_t* in, bf16_t* out, hipStream_t stream);

@@ -1,0 +1,728 @@
+// Memory-bound helper kernels: bit-exact index ops (window partition / reverse / roll / pixel
+// shuffle / mask / relative-position index), weight pack / gradient unpack, image pre/post
+// processing, the 3-channel stem conv, small-Cout conv gradients, L1 loss, fused AdamW + global-norm
+// clip, and the on-device probe of the transposing LDS read.
+#include "pack.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// index ops (reference network_swinir.py:33-62, :249-252, :269-272, nn.PixelShuffle) -- pure copies
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void window_partition_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C, int ws,
+                                        int reverse) {
+  const long long total = (long long)B * H * W * C;
+  const int nWw = W / ws, nW = (H / ws) * nWw, N = ws * ws;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const long long row = idx / C;                  // window-order row
+    const int p = (int)(row % N);
+    const long long b_ = row / N;
+    const int w = (int)(b_ % nW);
+    const long long b = b_ / nW;
+    const int y = (w / nWw) * ws + p / ws, xx = (w % nWw) * ws + p % ws;
+    const long long src = ((b * H + y) * W + xx) * C + c;
+    if (reverse) out[src] = x[idx]; else out[idx] = x[src];
+  }
+}
+
+template <typename T>
+__global__ void roll2d_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C, int sh, int sw) {
+  const long long total = (long long)B * H * W * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const long long b = t / H;
+    const int hs = ((h - sh) % H + H) % H, wsrc = ((w - sw) % W + W) % W;   // out[h,w] = x[(h-sh)%H, (w-sw)%W]
+    out[idx] = x[((b * H + hs) * W + wsrc) * C + c];
+  }
+}
+
+template <typename T>
+__global__ void pixel_shuffle_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int C, int H, int W, int r) {
+  // out[b, c, h*r+i, w*r+j] = in[b, c*r*r + i*r + j, h, w]
+  const long long total = (long long)B * C * r * r * H * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % (W * r));
+    long long t = idx / (W * r);
+    const int oy = (int)(t % (H * r)); t /= (H * r);
+    const int c = (int)(t % C);
+    const long long b = t / C;
+    const int h = oy / r, i = oy % r, w = ox / r, j = ox % r;
+    out[idx] = x[((b * C * r * r + (c * r * r + i * r + j)) * H + h) * W + w];
+  }
+}
+
+__global__ void shift_mask_kernel(float* __restrict__ mask, int H, int W, int ws, int shift) {
+  const int nWw = W / ws, nW = (H / ws) * nWw, N = ws * ws;
+  const long long total = (long long)nW * N * N;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % N), p = (int)((idx / N) % N), w = (int)(idx / ((long long)N * N));
+    auto lab = [&](int t) {
+      const int y = (w / nWw) * ws + t / ws, x = (w % nWw) * ws + t % ws;
+      const int ly = y < H - ws ? 0 : (y < H - shift ? 1 : 2);
+      const int lx = x < W - ws ? 0 : (x < W - shift ? 1 : 2);
+      return ly * 3 + lx;
+    };
+    mask[idx] = lab(p) != lab(q) ? -100.0f : 0.0f;
+  }
+}
+
+__global__ void rel_pos_index_kernel(long long* __restrict__ out, int ws) {
+  const int N = ws * ws;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  const int p = idx / N, q = idx % N;
+  out[idx] = (long long)((p / ws - q / ws + ws - 1) * (2 * ws - 1) + (p % ws - q % ws + ws - 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack / unpack
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pack_map(const PackDesc& d, int n, int k, long long& idx) {
+  int o;
+  if (d.nmap == NM_DIRECT) {
+    if (n >= d.Nreal) return false;
+    o = n;
+  } else if (d.nmap == NM_QKV) {
+    const int which = n / d.CA, rem = n - which * d.CA;
+    const int h = rem >> 5, dd = rem & 31;
+    if (which >= 3 || dd >= d.dh) return false;
+    o = which * (d.nH * d.dh) + h * d.dh + dd;
+  } else {
+    const int ij = n / d.Cs, c = n - ij * d.Cs;
+    if (ij >= d.r * d.r) return false;
+    o = c * d.r * d.r + ij;
+    if (o >= d.Nreal) return false;
+  }
+  if (d.kind == PK_VEC) {
+    idx = o;
+    return true;
+  }
+  if (d.kind == PK_LINEAR) {
+    int i;
+    if (d.kmap == KM_DIRECT) {
+      if (k >= d.Kreal) return false;
+      i = k;
+    } else {
+      const int h = k >> 5, dd = k & 31;
+      if (h >= d.nH || dd >= d.dh) return false;
+      i = h * d.dh + dd;
+    }
+    idx = (long long)o * d.Kreal + i;
+    return true;
+  }
+  const int tap = k / d.CinP, ci = k - tap * d.CinP;   // PK_CONV
+  if (ci >= d.Kreal) return false;
+  idx = ((long long)o * d.Kreal + ci) * 9 + tap;
+  return true;
+}
+
+__device__ __forceinline__ int find_desc(const PackDesc* descs, int ndesc, int blk) {
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int ndesc,
+                                                   const float* __restrict__ params, bf16_t* __restrict__ packed,
+                                                   float* __restrict__ side) {
+  const int di = find_desc(descs, ndesc, blockIdx.x);
+  const PackDesc d = descs[di];
+  const long long base = (long long)(blockIdx.x - d.blk0) * 1024 + threadIdx.x;
+  if (d.kind == PK_RPB) {
+    const int total = d.nH * 4096;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long e = base + 256 * u;
+      if (e >= total) break;
+      const int h = (int)(e >> 12), i = (int)((e >> 6) & 63), j = (int)(e & 63);
+      const int t = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+      side[d.dst + e] = params[d.src + t * d.nH + h];
+    }
+    return;
+  }
+  if (d.kind == PK_VEC) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long e = base + 256 * u;
+      if (e >= d.NP) break;
+      long long idx;
+      side[d.dst + e] = pack_map(d, (int)e, 0, idx) ? params[d.src + idx] : 0.f;
+    }
+    return;
+  }
+  const long long total = (long long)d.NP * d.KP;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long e = base + 256 * u;   // destination-linear index
+    if (e >= total) break;
+    int n, k;
+    if (!d.transpose) {
+      n = (int)(e / d.KP);
+      k = (int)(e - (long long)n * d.KP);
+    } else if (d.kind == PK_LINEAR) {
+      k = (int)(e / d.NP);
+      n = (int)(e - (long long)k * d.NP);
+    } else {  // conv transposed: dst[ci][tap'][n], tap' = 8 - tap
+      n = (int)(e % d.NP);
+      const long long t2 = e / d.NP;
+      const int tapf = (int)(t2 % 9), ci = (int)(t2 / 9);
+      k = (8 - tapf) * d.CinP + ci;
+    }
+    long long idx;
+    const float v = pack_map(d, n, k, idx) ? params[d.src + idx] : 0.f;
+    packed[d.dst + e] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(const PackDesc* __restrict__ descs, int ndesc,
+                                                     const float* __restrict__ gw, const float* __restrict__ gside,
+                                                     float* __restrict__ grads) {
+  const int di = find_desc(descs, ndesc, blockIdx.x);
+  const PackDesc d = descs[di];
+  if (d.transpose || d.kind == PK_RPB) return;
+  const long long base = (long long)(blockIdx.x - d.blk0) * 1024 + threadIdx.x;
+  const long long total = d.kind == PK_VEC ? d.NP : (long long)d.NP * d.KP;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long e = base + 256 * u;
+    if (e >= total) break;
+    long long idx;
+    if (d.kind == PK_VEC) {
+      if (pack_map(d, (int)e, 0, idx)) grads[d.src + idx] += gside[d.dst + e];
+    } else {
+      const int n = (int)(e / d.KP), k = (int)(e - (long long)n * d.KP);
+      if (pack_map(d, n, k, idx)) grads[d.src + idx] += gw[d.dst + e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// image pre-processing and the stem conv (network_swinir.py:783-788, :809-810, :814)
+// ------------------------------------------------------------------------------------------------
+// x NCHW fp32 [B][Cimg][H0][W0] -> NHWC fp32 [B][H][W][4]: reflect pad bottom/right, (x-mean)*range
+__global__ void img_prep_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int Cimg, int H0, int W0,
+                                int H, int W, float range, float m0, float m1, float m2) {
+  const long long total = (long long)B * H * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int xx = (int)(idx % W);
+    const int y = (int)((idx / W) % H);
+    const long long b = idx / ((long long)W * H);
+    const int ys = y < H0 ? y : 2 * (H0 - 1) - y, xs = xx < W0 ? xx : 2 * (W0 - 1) - xx;   // 'reflect'
+    const float mean[3] = {m0, m1, m2};
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cimg && c < 4; ++c) v[c] = (x[((b * Cimg + c) * H0 + ys) * W0 + xs] - mean[c < 3 ? c : 0]) * range;
+    *reinterpret_cast<float4*>(out + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// conv_first: in NHWC fp32 [B][H][W][4], weight fp32 [C][Cin][3][3], out fp32 [B*H*W][CP] (pad cols 0)
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                        int H, int W, int Cin, int C, int CP) {
+  extern __shared__ float sm[];
+  float* wl = sm;                 // [36][CP]  (tap*4 + ci)
+  float* pl = sm + 36 * CP;       // [16][36]
+  for (int i = threadIdx.x; i < 36 * CP; i += 256) {
+    const int kk = i / CP, c = i % CP;
+    const int tap = kk >> 2, ci = kk & 3;
+    wl[i] = (c < C && ci < Cin) ? wgt[((c * Cin) + ci) * 9 + tap] : 0.f;
+  }
+  const long long pix0 = (long long)blockIdx.x * 16;
+  const long long npix = (long long)B * H * W;
+  for (int i = threadIdx.x; i < 16 * 9; i += 256) {
+    const int pp = i / 9, tap = i % 9;
+    const long long pix = pix0 + pp;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix < npix) {
+      const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+      const long long b = pix / ((long long)W * H);
+      const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W)
+        v = *reinterpret_cast<const float4*>(in + ((b * H + yy) * W + xs) * 4);
+    }
+    *reinterpret_cast<float4*>(pl + pp * 36 + tap * 4) = v;
+  }
+  __syncthreads();
+  const int q = CP / 4;
+  for (int item = threadIdx.x; item < 16 * q; item += 256) {
+    const int pp = item / q, c4 = (item % q) * 4;
+    const long long pix = pix0 + pp;
+    if (pix >= npix) continue;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < 36; ++kk) {
+      const float pv = pl[pp * 36 + kk];
+      const float4 wv = *reinterpret_cast<const float4*>(wl + kk * CP + c4);
+      a0 += pv * wv.x; a1 += pv * wv.y; a2 += pv * wv.z; a3 += pv * wv.w;
+    }
+    a0 += c4 < C ? bias[c4] : 0.f;
+    a1 += c4 + 1 < C ? bias[c4 + 1] : 0.f;
+    a2 += c4 + 2 < C ? bias[c4 + 2] : 0.f;
+    a3 += c4 + 3 < C ? bias[c4 + 3] : 0.f;
+    *reinterpret_cast<float4*>(out + pix * CP + c4) = make_float4(a0, a1, a2, a3);
+  }
+}
+
+// conv_first weight/bias gradient: dW[c][ci][tap] += sum_pix gy[pix][c] * in[pix+off][ci]
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gy,
+                                                         float* __restrict__ dW, float* __restrict__ db, int B, int H,
+                                                         int W, int Cin, int C, int CP, int pix_per_block) {
+  __shared__ float pl[64 * 36];
+  const long long npix = (long long)B * H * W;
+  const long long p_begin = (long long)blockIdx.x * pix_per_block;
+  const long long p_end = p_begin + pix_per_block < npix ? p_begin + pix_per_block : npix;
+  const int c = threadIdx.x;
+  float acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.f;
+  float accb = 0.f;
+  for (long long pb = p_begin; pb < p_end; pb += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 9; i += 256) {
+      const int pp = i / 9, tap = i % 9;
+      const long long pix = pb + pp;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < p_end) {
+        const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W)
+          v = *reinterpret_cast<const float4*>(in + ((b * H + yy) * W + xs) * 4);
+      }
+      *reinterpret_cast<float4*>(pl + pp * 36 + tap * 4) = v;
+    }
+    __syncthreads();
+    if (c < C) {
+      const int cnt = (int)(p_end - pb < 64 ? p_end - pb : 64);
+      for (int pp = 0; pp < cnt; ++pp) {
+        const float g = gy[(pb + pp) * CP + c];
+        accb += g;
+#pragma unroll
+        for (int kk = 0; kk < 36; ++kk) acc[kk] += g * pl[pp * 36 + kk];
+      }
+    }
+  }
+  if (c < C) {
+    for (int tap = 0; tap < 9; ++tap)
+      for (int ci = 0; ci < Cin; ++ci) atomicAdd(dW + (c * Cin + ci) * 9 + tap, acc[tap * 4 + ci]);
+    atomicAdd(db + c, accb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small-Cout convs (image heads: conv_last 64->3, light upsample C->r*r*3): gradients on the VALU
+// ------------------------------------------------------------------------------------------------
+// gy image gradient prep: dpred NCHW fp32 [B][Cimg][Hc][Wc] (cropped HR size) -> NHWC fp32
+// [B][H][W][CoP] of the conv output (before PixelShuffle if r>1), scaled by inv_range; zero outside the crop.
+__global__ void img_grad_prep_kernel(const float* __restrict__ dpred, float* __restrict__ gy, int B, int Cimg, int Hc,
+                                     int Wc, int H, int W, int r, int CoP, float inv_range) {
+  const long long total = (long long)B * H * W * CoP;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % CoP);
+    long long t = idx / CoP;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const long long b = t / H;
+    const int rr = r * r;
+    const int c = n / rr, ij = n % rr;
+    const int oy = y * r + ij / r, ox = x * r + ij % r;
+    float v = 0.f;
+    if (c < Cimg && oy < Hc && ox < Wc) v = dpred[((b * Cimg + c) * Hc + oy) * Wc + ox] * inv_range;
+    gy[idx] = v;
+  }
+}
+
+// dX[pix][ci] = sum_tap sum_co gy[pix - off(tap)][co] * W[co][ci][tap]  -> bf16 NHWC [pix][CinP]
+__global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wgt,
+                                                              bf16_t* __restrict__ dx, int B, int H, int W, int Cin,
+                                                              int CinP, int Co, int CoP) {
+  extern __shared__ float sm[];
+  float* wl = sm;                       // [9][Co][CinP]
+  float* gl = sm + 9 * Co * CinP;       // [16 pixels][9][CoP]
+  for (int i = threadIdx.x; i < 9 * Co * CinP; i += 256) {
+    const int ci = i % CinP, co = (i / CinP) % Co, tap = i / (CinP * Co);
+    wl[i] = ci < Cin ? wgt[((co * Cin) + ci) * 9 + tap] : 0.f;
+  }
+  const long long npix = (long long)B * H * W;
+  const long long pix0 = (long long)blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * 9 * CoP; i += 256) {
+    const int n = i % CoP, tap = (i / CoP) % 9, pp = i / (9 * CoP);
+    const long long pix = pix0 + pp;
+    float v = 0.f;
+    if (pix < npix) {
+      const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+      const long long b = pix / ((long long)W * H);
+      // output pixel that used input pixel (y,xx) through tap (ky,kx) is (y - (ky-1), xx - (kx-1))
+      const int yy = y - (tap / 3 - 1), xs = xx - (tap % 3 - 1);
+      if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) v = gy[((b * H + yy) * W + xs) * CoP + n];
+    }
+    gl[i] = v;
+  }
+  __syncthreads();
+  const int q = CinP / 4;
+  for (int item = threadIdx.x; item < 16 * q; item += 256) {
+    const int pp = item / q, c4 = (item % q) * 4;
+    const long long pix = pix0 + pp;
+    if (pix >= npix) continue;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int tap = 0; tap < 9; ++tap)
+      for (int co = 0; co < Co; ++co) {
+        const float g = gl[(pp * 9 + tap) * CoP + co];
+        const float4 wv = *reinterpret_cast<const float4*>(wl + (tap * Co + co) * CinP + c4);
+        a0 += g * wv.x; a1 += g * wv.y; a2 += g * wv.z; a3 += g * wv.w;
+      }
+    *reinterpret_cast<uint2*>(dx + pix * CinP + c4) = pack_bf4(a0, a1, a2, a3);
+  }
+}
+
+// dW[co][ci][tap] += sum_q X[q][ci] * gy[q - off(tap)][co];  db[co] += sum gy.  blockDim = CinP threads.
+__global__ void smallconv_wgrad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dW,
+                                       float* __restrict__ db, int B, int H, int W, int Cin, int CinP, int Co, int CoP,
+                                       int pix_per_block) {
+  extern __shared__ float gl[];         // [64 pixels][9][CoP]
+  const long long npix = (long long)B * H * W;
+  const long long p_begin = (long long)blockIdx.x * pix_per_block;
+  const long long p_end = p_begin + pix_per_block < npix ? p_begin + pix_per_block : npix;
+  const int ci = threadIdx.x;
+  constexpr int MAXACC = 9 * 16;
+  float acc[MAXACC];
+#pragma unroll
+  for (int i = 0; i < MAXACC; ++i) acc[i] = 0.f;
+  float accb = 0.f;
+  for (long long pb = p_begin; pb < p_end; pb += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 9 * CoP; i += blockDim.x) {
+      const int n = i % CoP, tap = (i / CoP) % 9, pp = i / (9 * CoP);
+      const long long pix = pb + pp;
+      float v = 0.f;
+      if (pix < p_end) {
+        const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        const int yy = y - (tap / 3 - 1), xs = xx - (tap % 3 - 1);
+        if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) v = gy[((b * H + yy) * W + xs) * CoP + n];
+      }
+      gl[i] = v;
+    }
+    __syncthreads();
+    const int cnt = (int)(p_end - pb < 64 ? p_end - pb : 64);
+    for (int pp = 0; pp < cnt; ++pp) {
+      const float xv = bf2f(x[(pb + pp) * CinP + ci]);
+      if (ci < Co) accb += gl[(pp * 9 + 4) * CoP + ci];   // centre tap == gy at this pixel
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int co = 0; co < 16; ++co)
+          if (co < Co) acc[tap * 16 + co] += xv * gl[(pp * 9 + tap) * CoP + co];
+    }
+  }
+  if (ci < Cin) {
+    for (int tap = 0; tap < 9; ++tap)
+      for (int co = 0; co < Co; ++co) atomicAdd(dW + ((co * Cin) + ci) * 9 + tap, acc[tap * 16 + co]);
+  }
+  if (ci < Co) atomicAdd(db + ci, accb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void add_f32_bf16_kernel(float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ ab,
+                                    long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 x = reinterpret_cast<float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    reinterpret_cast<float4*>(a)[i] = x;
+    if (ab) reinterpret_cast<uint2*>(ab)[i] = pack_bf4(x.x, x.y, x.z, x.w);
+  }
+}
+
+__global__ void add_bf16_into_f32_kernel(float* __restrict__ a, const bf16_t* __restrict__ b, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 x = reinterpret_cast<float4*>(a)[i];
+    const uint2 u = reinterpret_cast<const uint2*>(b)[i];
+    float y0, y1, y2, y3;
+    unpack_bf2(u.x, y0, y1);
+    unpack_bf2(u.y, y2, y3);
+    x.x += y0; x.y += y1; x.z += y2; x.w += y3;
+    reinterpret_cast<float4*>(a)[i] = x;
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ a, bf16_t* __restrict__ out, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i];
+    reinterpret_cast<uint2*>(out)[i] = pack_bf4(x.x, x.y, x.z, x.w);
+  }
+}
+
+// d(LeakyReLU) applied in place to a bf16 gradient: g *= (act > 0 ? 1 : slope)
+__global__ void dlrelu_bf16_kernel(bf16_t* __restrict__ g, const bf16_t* __restrict__ act, float slope, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float a = bf2f(act[i]);
+    if (!(a > 0.f)) g[i] = f2bf(bf2f(g[i]) * slope);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// L1 loss (finetune_swinir.py:66-67) forward + backward, with a non-finite counter (:133-143)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      float* __restrict__ dpred, float* __restrict__ loss_sum,
+                                                      unsigned* __restrict__ nonfinite, long long n, float inv_n,
+                                                      float grad_scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  unsigned bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float p = pred[i], d = p - target[i];
+    s += fabsf(d);
+    bad += !isfinite(p);
+    if (dpred) dpred[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n * grad_scale;
+  }
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if (bad) atomicAdd(nonfinite, bad);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// global-norm clip + AdamW (torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW semantics,
+// finetune_swinir.py:168-171, :303)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = g[i];
+    s += v * v;
+  }
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    const float* __restrict__ sumsq, float max_norm, float grad_div,
+                                                    float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt) {
+  float coef = 1.0f / grad_div;
+  if (max_norm > 0.f) {
+    const float total = sqrtf(*sumsq) / grad_div;
+    const float c = max_norm / (total + 1e-6f);
+    coef *= c < 1.0f ? c : 1.0f;
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// probe: contract of ds_read_b64_tr_b16 as used by lds_tr_read/tr_addr (common.h)
+// ------------------------------------------------------------------------------------------------
+// in: [64][16] u16 tile.  out[lane*8 + jj] = fragment element jj of lane, expected = in[8*(lane>>4)+jj][lane&15]
+__global__ void probe_trread_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 24];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 64 * 16; i += 64) tile[(i >> 4) * 24 + (i & 15)] = in[i];
+  __syncthreads();
+  const int g = lane >> 4;
+  const bf16x4_t lo = lds_tr_read(tr_addr(tile, 24, 8 * g, 0, lane));
+  const bf16x4_t hi = lds_tr_read(tr_addr(tile, 24, 8 * g + 4, 0, lane));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    out[lane * 8 + e] = (bf16_t)lo[e];
+    out[lane * 8 + 4 + e] = (bf16_t)hi[e];
+  }
+}
+
+inline int grid_for(long long n, int block = 256, int cap = 8192) {
+  long long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define ELEM_DISPATCH(KERNEL, ...)                                                                          \
+  if (elem_bytes == 4) hipLaunchKernelGGL(KERNEL<unsigned>, dim3(grid), dim3(256), 0, stream, (const unsigned*)x, (unsigned*)out, __VA_ARGS__); \
+  else if (elem_bytes == 2) hipLaunchKernelGGL(KERNEL<unsigned short>, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, (unsigned short*)out, __VA_ARGS__); \
+  else if (elem_bytes == 8) hipLaunchKernelGGL(KERNEL<unsigned long long>, dim3(grid), dim3(256), 0, stream, (const unsigned long long*)x, (unsigned long long*)out, __VA_ARGS__); \
+  else { srk_set_error("index op: unsupported element size %d", elem_bytes); return SRK_E_UNSUPPORTED; }
+
+int srk_launch_window_partition(const void* x, void* out, int B, int H, int W, int C, int ws, int elem_bytes,
+                                int reverse, hipStream_t stream) {
+  const int grid = grid_for((long long)B * H * W * C);
+  ELEM_DISPATCH(window_partition_kernel, B, H, W, C, ws, reverse)
+  return srk_check_launch("window_partition");
+}
+
+int srk_launch_roll2d(const void* x, void* out, int B, int H, int W, int C, int sh, int sw, int elem_bytes,
+                      hipStream_t stream) {
+  const int grid = grid_for((long long)B * H * W * C);
+  ELEM_DISPATCH(roll2d_kernel, B, H, W, C, sh, sw)
+  return srk_check_launch("roll2d");
+}
+
+int srk_launch_pixel_shuffle(const void* x, void* out, int B, int C, int H, int W, int r, int elem_bytes,
+                             hipStream_t stream) {
+  const int grid = grid_for((long long)B * C * r * r * H * W);
+  ELEM_DISPATCH(pixel_shuffle_kernel, B, C, H, W, r)
+  return srk_check_launch("pixel_shuffle");
+}
+
+int srk_launch_shift_mask(float* mask, int H, int W, int ws, int shift, hipStream_t stream) {
+  const long long total = (long long)(H / ws) * (W / ws) * ws * ws * ws * ws;
+  hipLaunchKernelGGL(shift_mask_kernel, dim3(grid_for(total)), dim3(256), 0, stream, mask, H, W, ws, shift);
+  return srk_check_launch("shift_mask");
+}
+
+int srk_launch_rel_pos_index(long long* out, int ws, hipStream_t stream) {
+  const int n = ws * ws * ws * ws;
+  hipLaunchKernelGGL(rel_pos_index_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, ws);
+  return srk_check_launch("rel_pos_index");
+}
+
+int srk_launch_pack(const PackDesc* d_descs, int ndesc, int total_blocks, const float* params, bf16_t* packed,
+                    float* side, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, ndesc, params, packed, side);
+  return srk_check_launch("pack");
+}
+
+int srk_launch_unpack_grads(const PackDesc* d_descs, int ndesc, int total_blocks, const float* gstage_w,
+                            const float* gstage_side, float* grads, hipStream_t stream) {
+  hipLaunchKernelGGL(unpack_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, ndesc, gstage_w, gstage_side, grads);
+  return srk_check_launch("unpack_grads");
+}
+
+int srk_launch_img_prep(const float* x, float* out, int B, int Cimg, int H0, int W0, int H, int W, float range,
+                        const float* mean, hipStream_t stream) {
+  hipLaunchKernelGGL(img_prep_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, stream, x, out, B, Cimg, H0, W0,
+                     H, W, range, mean[0], mean[1], mean[2]);
+  return srk_check_launch("img_prep");
+}
+
+int srk_launch_stem_conv(const float* in, const float* wgt, const float* bias, float* out, int B, int H, int W, int Cin,
+                         int C, int CP, hipStream_t stream) {
+  SRK_REQUIRE(Cin <= 4 && CP % 4 == 0, SRK_E_SHAPE, "stem conv: Cin=%d > 4 unsupported", Cin);
+  const size_t lds = (size_t)(36 * CP + 16 * 36) * sizeof(float);
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), lds, stream, in, wgt, bias, out, B, H,
+                     W, Cin, C, CP);
+  return srk_check_launch("stem_conv");
+}
+
+int srk_launch_stem_wgrad(const float* in, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int C,
+                          int CP, hipStream_t stream) {
+  SRK_REQUIRE(C <= 256 && Cin <= 4, SRK_E_SHAPE, "stem wgrad: C=%d > 256 or Cin=%d > 4 unsupported", C, Cin);
+  const long long npix = (long long)B * H * W;
+  const int ppb = 256;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, stream, in, gy, dW, db, B,
+                     H, W, Cin, C, CP, ppb);
+  return srk_check_launch("stem_wgrad");
+}
+
+int srk_launch_img_grad_prep(const float* dpred, float* gy, int B, int Cimg, int Hc, int Wc, int H, int W, int r, int CoP,
+                             float inv_range, hipStream_t stream) {
+  hipLaunchKernelGGL(img_grad_prep_kernel, dim3(grid_for((long long)B * H * W * CoP)), dim3(256), 0, stream, dpred, gy, B,
+                     Cimg, Hc, Wc, H, W, r, CoP, inv_range);
+  return srk_check_launch("img_grad_prep");
+}
+
+int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP,
+                               int Co, int CoP, hipStream_t stream) {
+  SRK_REQUIRE(Co <= 16 && Co <= CoP, SRK_E_SHAPE, "smallconv dgrad: Co=%d", Co);
+  const size_t lds = (size_t)(9 * Co * CinP + 16 * 9 * CoP) * sizeof(float);
+  SRK_REQUIRE(lds <= 64 * 1024, SRK_E_SHAPE, "smallconv dgrad: LDS %zu too large", lds);
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(smallconv_dgrad_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), lds, stream, gy, wgt, dx, B, H,
+                     W, Cin, CinP, Co, CoP);
+  return srk_check_launch("smallconv_dgrad");
+}
+
+int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin,
+                               int CinP, int Co, int CoP, hipStream_t stream) {
+  SRK_REQUIRE(Co <= 16 && CinP <= 1024 && CinP % 64 == 0, SRK_E_SHAPE, "smallconv wgrad: Co=%d CinP=%d", Co, CinP);
+  const size_t lds = (size_t)64 * 9 * CoP * sizeof(float);
+  const long long npix = (long long)B * H * W;
+  const int ppb = 1024;
+  hipLaunchKernelGGL(smallconv_wgrad_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(CinP), lds, stream, x, gy, dW,
+                     db, B, H, W, Cin, CinP, Co, CoP, ppb);
+  return srk_check_launch("smallconv_wgrad");
+}
+
+int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream) {
+  SRK_REQUIRE(n % 4 == 0, SRK_E_SHAPE, "add: n %% 4 != 0");
+  hipLaunchKernelGGL(add_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a, b, ab, n / 4);
+  return srk_check_launch("add");
+}
+
+int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStream_t stream) {
+  SRK_REQUIRE(n % 4 == 0, SRK_E_SHAPE, "add: n %% 4 != 0");
+  hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a, b, n / 4);
+  return srk_check_launch("add_bf16");
+}
+
+int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream) {
+  SRK_REQUIRE(n % 4 == 0, SRK_E_SHAPE, "cast: n %% 4 != 0");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a, out, n / 4);
+  return srk_check_launch("cast");
+}
+
+int srk_launch_dlrelu_bf16(bf16_t* g, const bf16_t* act, float slope, long long n, hipStream_t stream) {
+  hipLaunchKernelGGL(dlrelu_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, g, act, slope, n);
+  return srk_check_launch("dlrelu");
+}
+
+int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, float* loss_sum, unsigned* nonfinite,
+                       long long n, float grad_scale, hipStream_t stream) {
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, stream, pred, target, dpred, loss_sum,
+                     nonfinite, n, 1.0f / (float)n, grad_scale);
+  return srk_check_launch("l1_loss");
+}
+
+int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, stream, g, n, out);
+  return srk_check_launch("sumsq");
+}
+
+int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float max_norm,
+                     float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step,
+                     hipStream_t stream) {
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, sumsq, max_norm,
+                     grad_div, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
+  return srk_check_launch("adamw");
+}
+
+int srk_launch_probe_trread(const bf16_t* in, bf16_t* out, hipStream_t stream) {
+  hipLaunchKernelGGL(probe_trread_kernel, dim3(1), dim3(64), 0, stream, in, out);
+  return srk_check_launch("probe_trread");
+}

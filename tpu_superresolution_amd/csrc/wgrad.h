@@ -1,0 +1,20 @@
+// Internal interface of the weight-gradient GEMM (wgrad.hip).
+#pragma once
+#include "common.h"
+
+struct WgradParams {
+  const bf16_t* Y;   // [M][ldy] bf16: gradient of the layer output (conv+PixelShuffle: stored shuffled, see r/Cs)
+  int ldy;
+  const bf16_t* X;   // [M][ldx] bf16: layer input (conv: NHWC, ldx = CinP)
+  int ldx;
+  int M, N, K;       // conv: K = CinP (per tap)
+  float* dW;         // fp32 staging gradient, packed layout [N][ldw]
+  int ldw;           // linear: K ; conv: 9*CinP
+  float* db;         // fp32 [N] or null
+  int m_per;         // rows per workgroup (set by the launcher)
+  int conv;          // 0 linear, 1 conv3x3
+  int B, H, W;       // conv geometry
+  int r, Cs;         // conv: Y stored pixel-shuffled with factor r, Cs stored channels (r <= 1: plain)
+};
+
+int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);

@@ -1,0 +1,217 @@
+// Weight-gradient GEMM for linear layers and 3x3 convs (gfx950, v_mfma_f32_16x16x32_bf16):
+//
+//   dW[n][k] += sum_m Y[m][n] * X[m][k]          (Y = grad of the layer output, X = layer input)
+//   db[n]    += sum_m Y[m][n]
+//
+// Both operands are stored with the reduction index m as the slow (row) dimension, which is the
+// transpose of what the MFMA A/B fragments want (8 consecutive k per lane).  Row tiles of 64 m are
+// staged into LDS as they lie in memory (coalesced 16-B pieces) and the fragments are fetched with
+// the hardware transposing read ds_read_b64_tr_b16.  A workgroup (4 waves, 2x2) owns a
+// (64*TA) x (64*TB) tile of dW and a contiguous slice of m; partial sums are added to the fp32
+// staging gradient (packed [NP][KP] layout) with float atomics (contiguous 64-B runs per 16 lanes).
+// The bias gradient comes for free from one extra MFMA column against an all-ones B fragment.
+#include "wgrad.h"
+
+namespace {
+
+template <int TA, int TB, bool CONV>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int TN = 64 * TA, TK = 64 * TB;
+  constexpr int SY = TN + 8, SX = TK + 8;          // LDS row strides (elements)
+  constexpr int PY = (64 * TN / 8) / 256;          // 16-B pieces per thread
+  constexpr int PX = (64 * TK / 8) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ys = reinterpret_cast<bf16_t*>(smem);    // [2][64][SY]
+  bf16_t* Xs = Ys + 2 * 64 * SY;                   // [2][64][SX]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int ntn = p.N / TN, ntk = p.K / TK;
+  int bx = blockIdx.x;
+  const int tn = bx % ntn; bx /= ntn;
+  const int tk = bx % ntk; bx /= ntk;
+  const int tap = bx;                               // 0 unless CONV
+  const int n0 = tn * TN, k0 = tk * TK;
+  const int dy = CONV ? tap / 3 - 1 : 0, dx = CONV ? tap % 3 - 1 : 0;
+  const int m_begin = blockIdx.y * p.m_per;
+  const int m_end = min(p.M, m_begin + p.m_per);
+  const int nchunk = (m_end - m_begin + 63) / 64;
+  if (nchunk <= 0) return;
+
+  uint4 ry[PY], rx[PX];
+  auto load_stage = [&](int ch) {
+    const int mb = m_begin + ch * 64;
+#pragma unroll
+    for (int t = 0; t < PY; ++t) {
+      const int pid = tid + 256 * t;
+      const int row = pid / (TN / 8), c8 = pid % (TN / 8);
+      const int m = mb + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        if (CONV && p.r > 1) {
+          const int hw = p.H * p.W;
+          const int b = m / hw, rem = m - b * hw;
+          const int y = rem / p.W, x = rem - y * p.W;
+          const int nn = n0 + c8 * 8;
+          const int ij = nn / p.Cs, c = nn - ij * p.Cs;
+          const int si = ij / p.r, sj = ij - si * p.r;
+          v = *reinterpret_cast<const uint4*>(
+              p.Y + (((long long)(b * p.H * p.r + y * p.r + si)) * (p.W * p.r) + x * p.r + sj) * p.Cs + c);
+        } else {
+          v = *reinterpret_cast<const uint4*>(p.Y + (long long)m * p.ldy + n0 + c8 * 8);
+        }
+      }
+      ry[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < PX; ++t) {
+      const int pid = tid + 256 * t;
+      const int row = pid / (TK / 8), c8 = pid % (TK / 8);
+      const int m = mb + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        if (CONV) {
+          const int hw = p.H * p.W;
+          const int b = m / hw, rem = m - b * hw;
+          const int y = rem / p.W + dy, x = rem % p.W + dx;
+          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+            v = *reinterpret_cast<const uint4*>(p.X + ((long long)(b * p.H + y) * p.W + x) * p.ldx + k0 + c8 * 8);
+        } else {
+          v = *reinterpret_cast<const uint4*>(p.X + (long long)m * p.ldx + k0 + c8 * 8);
+        }
+      }
+      rx[t] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    bf16_t* ys = Ys + buf * 64 * SY;
+    bf16_t* xs = Xs + buf * 64 * SX;
+#pragma unroll
+    for (int t = 0; t < PY; ++t) {
+      const int pid = tid + 256 * t;
+      *reinterpret_cast<uint4*>(ys + (pid / (TN / 8)) * SY + (pid % (TN / 8)) * 8) = ry[t];
+    }
+#pragma unroll
+    for (int t = 0; t < PX; ++t) {
+      const int pid = tid + 256 * t;
+      *reinterpret_cast<uint4*>(xs + (pid / (TK / 8)) * SX + (pid % (TK / 8)) * 8) = rx[t];
+    }
+  };
+
+  constexpr int NTW = 2 * TA, KTW = 2 * TB;       // 16-tiles per wave
+  f32x4_t acc[NTW][KTW], accb[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.db != nullptr && tk == 0 && wk == 0 && tap == 0;
+  const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) load_stage(ch + 1);
+    const bf16_t* ys = Ys + buf * 64 * SY;
+    const bf16_t* xs = Xs + buf * 64 * SX;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yf[NTW], xf[KTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int c0 = wn * (32 * TA) + 16 * i;
+        const bf16x4_t lo = lds_tr_read(tr_addr(ys, SY, 32 * ks + 8 * g, c0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(ys, SY, 32 * ks + 8 * g + 4, c0, lane));
+        yf[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) {
+        const int c0 = wk * (32 * TB) + 16 * j;
+        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SX, 32 * ks + 8 * g, c0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SX, 32 * ks + 8 * g + 4, c0, lane));
+        xf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < nchunk) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // acc[i][j][e] = dW[n = n0 + wn*32TA + 16i + 4g + e][k = k0 + wk*32TB + 16j + r16]
+  const long long koff = CONV ? (long long)tap * p.K : 0;
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int n = n0 + wn * (32 * TA) + 16 * i + 4 * g;
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const int k = k0 + wk * (32 * TB) + 16 * j + r16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + koff + k, acc[i][j][e]);
+    }
+    if (do_bias && r16 == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.db + n + e, accb[i][e]);
+    }
+  }
+}
+
+template <int TA, int TB, bool CONV>
+int launch(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * 64 * ((64 * TA + 8) + (64 * TB + 8)) * sizeof(bf16_t);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, TB, CONV>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      srk_set_error("wgrad: cannot reserve %zu bytes of LDS", lds);
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  const int tiles = (p.N / (64 * TA)) * (p.K / (64 * TB)) * (CONV ? 9 : 1);
+  WgradParams q = p;
+  // aim at ~2 workgroups per CU worth of work items, at least 256 rows each
+  int splits = cdiv(512, tiles);
+  int m_per = round_up(cdiv(p.M, splits), 64);
+  if (m_per < 256) m_per = 256;
+  q.m_per = m_per;
+  splits = cdiv(p.M, m_per);
+  hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles, splits), dim3(256), lds, stream, q);
+  return srk_check_launch("wgrad");
+}
+
+template <bool CONV>
+int dispatch(const WgradParams& p, hipStream_t stream) {
+  const int a = p.N % 192 == 0 ? 3 : (p.N % 128 == 0 ? 2 : 1);
+  const int b = p.K % 192 == 0 ? 3 : (p.K % 128 == 0 ? 2 : 1);
+#define WCASE(A, B) \
+  if (a == A && b == B) return launch<A, B, CONV>(p, stream);
+  WCASE(3, 3) WCASE(3, 1) WCASE(1, 3) WCASE(2, 2) WCASE(2, 1) WCASE(1, 2) WCASE(1, 1) WCASE(3, 2) WCASE(2, 3)
+#undef WCASE
+  srk_set_error("wgrad: no tile for N=%d K=%d", p.N, p.K);
+  return SRK_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
+  SRK_REQUIRE(p.M > 0 && p.N % 64 == 0 && p.K % 64 == 0, SRK_E_SHAPE, "wgrad: bad M/N/K %d/%d/%d", p.M, p.N, p.K);
+  SRK_REQUIRE(p.Y && p.X && p.dW, SRK_E_NULL, "wgrad: null operand");
+  if (p.conv) {
+    SRK_REQUIRE(p.M == p.B * p.H * p.W, SRK_E_SHAPE, "wgrad(conv): M != B*H*W");
+    if (p.r > 1) SRK_REQUIRE(p.Cs % 8 == 0 && p.N == p.r * p.r * p.Cs, SRK_E_SHAPE, "wgrad(conv,ps): bad Cs");
+    return dispatch<true>(p, stream);
+  }
+  return dispatch<false>(p, stream);
+}

@@ -1,0 +1,187 @@
+"""Host-side driver of the libsrk SwinIR executor: plan, flat parameter/gradient buffers, packing,
+workspace and the autograd bridge.  PyTorch is used for device memory, streams and autograd
+plumbing only; all arithmetic happens in libsrk.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import SwinIRConfig, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ParamInfo:
+    __slots__ = ("name", "offset", "numel", "shape")
+
+    def __init__(self, name: str, offset: int, numel: int, shape: Tuple[int, ...]):
+        self.name, self.offset, self.numel, self.shape = name, offset, numel, shape
+
+
+class SwinIRPlan:
+    """Owns a srk_swinir_plan (host bookkeeping only)."""
+
+    def __init__(self, *, img_size: int, in_chans: int, embed_dim: int, depths: Sequence[int], num_heads: Sequence[int],
+                 window_size: int, mlp_ratio: float, upscale: int, img_range: float, upsampler: str,
+                 qk_scale: Optional[float] = None):
+        if upsampler == "pixelshuffle":
+            ups = _lib.UPSAMPLER_PIXELSHUFFLE
+        elif upsampler == "pixelshuffledirect":
+            ups = _lib.UPSAMPLER_PIXELSHUFFLEDIRECT
+        else:
+            raise _lib.SrkUnsupported(f"HIP path supports upsampler 'pixelshuffle' / 'pixelshuffledirect' (got {upsampler!r})")
+        if len(depths) != len(num_heads) or len(depths) > 16:
+            raise ValueError("depths / num_heads must have the same length (<= 16)")
+        cfg = SwinIRConfig()
+        cfg.img_size = int(img_size)
+        cfg.in_chans = int(in_chans)
+        cfg.embed_dim = int(embed_dim)
+        cfg.num_layers = len(depths)
+        for i, (d, h) in enumerate(zip(depths, num_heads)):
+            cfg.depths[i] = int(d)
+            cfg.num_heads[i] = int(h)
+        cfg.window_size = int(window_size)
+        cfg.hidden_dim = int(embed_dim * mlp_ratio)
+        cfg.upscale = int(upscale)
+        cfg.upsampler = ups
+        cfg.img_range = float(img_range)
+        mean = (0.4488, 0.4371, 0.4040) if in_chans == 3 else (0.0, 0.0, 0.0)   # network_swinir.py:658-662
+        for i in range(3):
+            cfg.mean[i] = mean[i]
+        cfg.qk_scale = float(qk_scale) if qk_scale else 0.0
+        self.cfg = cfg
+        self.upscale = int(upscale)
+        self.n_blocks = int(sum(depths))
+        handle = C.c_void_p()
+        check(lib().srk_swinir_plan_create(C.byref(cfg), C.byref(handle)))
+        self.handle = handle
+        self.param_floats = int(lib().srk_swinir_param_floats(handle))
+        self.params: List[ParamInfo] = []
+        name = C.c_char_p()
+        off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        for i in range(lib().srk_swinir_param_count(handle)):
+            check(lib().srk_swinir_param_info(handle, i, C.byref(name), C.byref(off), C.byref(numel), C.byref(ndim), C.byref(shape)))
+            self.params.append(ParamInfo(name.value.decode(), off.value, numel.value, tuple(shape[j] for j in range(ndim.value))))
+        self.num_segments = int(lib().srk_swinir_num_segments(handle))
+        self.segment_ranges: List[Tuple[int, int]] = []
+        b, e = C.c_int64(), C.c_int64()
+        for s in range(self.num_segments):
+            check(lib().srk_swinir_segment_range(handle, s, C.byref(b), C.byref(e)))
+            self.segment_ranges.append((b.value, e.value))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().srk_swinir_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class SwinIREngine:
+    """Device state for one model replica on one GPU."""
+
+    def __init__(self, plan: SwinIRPlan, device: torch.device):
+        self.plan = plan
+        self.device = device
+        self.flat = torch.zeros(plan.param_floats, dtype=torch.float32, device=device)
+        self.flat_grad: Optional[torch.Tensor] = None
+        self.const = torch.empty(max(1, lib().srk_swinir_const_bytes(plan.handle)), dtype=torch.uint8, device=device)
+        check(lib().srk_swinir_const_init(plan.handle, self.const.data_ptr(), _stream()))
+        self.packed = torch.empty(lib().srk_swinir_packed_bytes(plan.handle), dtype=torch.uint8, device=device)
+        self.workspace: Optional[torch.Tensor] = None
+        self._ws_key = None
+        self.packed_valid = False
+        self.segment_hook: Optional[Callable[[int, int, int], None]] = None
+
+    # -- parameters -------------------------------------------------------------------------------
+    def views(self, base: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {p.name: base[p.offset:p.offset + p.numel].view(p.shape) for p in self.plan.params}
+
+    def pack(self) -> None:
+        check(lib().srk_swinir_pack(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), _stream()))
+        self.packed_valid = True
+
+    def ensure_grad(self) -> torch.Tensor:
+        if self.flat_grad is None:
+            self.flat_grad = torch.zeros_like(self.flat)
+        return self.flat_grad
+
+    # -- execution --------------------------------------------------------------------------------
+    def _workspace(self, B: int, H: int, W: int, training: bool) -> torch.Tensor:
+        key = (B, H, W, bool(training))
+        need = lib().srk_swinir_workspace_bytes(self.plan.handle, B, H, W, int(training))
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ws_key = key
+        return self.workspace
+
+    def forward(self, x: torch.Tensor, training: bool, drop_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("SwinIR HIP path needs a GPU tensor; there is no CPU fallback in this package")
+        x = x.contiguous().float()
+        B, Cin, H, W = x.shape
+        if Cin != self.plan.cfg.in_chans:
+            raise ValueError(f"expected {self.plan.cfg.in_chans} input channels, got {Cin}")
+        if not self.packed_valid:
+            self.pack()
+        ws = self._workspace(B, H, W, training)
+        s = self.plan.upscale
+        y = torch.empty((B, Cin, H * s, W * s), dtype=torch.float32, device=self.device)
+        ds = drop_scale.contiguous().data_ptr() if drop_scale is not None else None
+        check(lib().srk_swinir_forward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                       ws.data_ptr(), B, H, W, int(training), ds, _stream()))
+        return y
+
+    def backward(self, d_y: torch.Tensor, shape: Tuple[int, int, int], drop_scale: Optional[torch.Tensor] = None) -> None:
+        """Accumulates parameter gradients into flat_grad; calls segment_hook(seg, begin, end) after each segment."""
+        B, H, W = shape
+        if self._ws_key != (B, H, W, True):
+            raise RuntimeError("backward without a matching training forward")
+        g = self.ensure_grad()
+        d_y = d_y.contiguous().float()
+        ds = drop_scale.contiguous().data_ptr() if drop_scale is not None else None
+        for seg in range(self.plan.num_segments):
+            check(lib().srk_swinir_backward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), g.data_ptr(),
+                                            d_y.data_ptr(), self.workspace.data_ptr(), B, H, W, ds, seg, seg + 1, _stream()))
+            if self.segment_hook is not None:
+                b, e = self.plan.segment_ranges[seg]
+                self.segment_hook(seg, b, e)
+
+    def activation(self, name: str, dtype: torch.dtype) -> torch.Tensor:
+        """Debug/parity view of a named workspace buffer (flat)."""
+        off, nbytes = C.c_size_t(), C.c_size_t()
+        check(lib().srk_swinir_workspace_lookup(self.plan.handle, name.encode(), C.byref(off), C.byref(nbytes)))
+        return self.workspace[off.value:off.value + nbytes.value].view(dtype)
+
+
+class _SwinIRFunction(torch.autograd.Function):
+    """Autograd bridge: one node for the whole model.  Parameter gradients are written by the C backward
+    straight into the engine's flat gradient buffer (p.grad are views of it), not returned to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, module, drop_scale, training):
+        eng: SwinIREngine = module._engine
+        y = eng.forward(x, training, drop_scale)
+        ctx.module = module
+        ctx.shape = (x.shape[0], x.shape[2], x.shape[3])
+        ctx.drop_scale = drop_scale
+        ctx.trained = training
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        module = ctx.module
+        if not ctx.trained:
+            raise RuntimeError("SwinIR forward was run without gradient tracking")
+        module._backward_into_flat(d_y, ctx.shape, ctx.drop_scale)
+        return None, None, None, None, None

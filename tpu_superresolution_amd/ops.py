@@ -1,0 +1,182 @@
+"""Thin torch wrappers over the building-block entry points of libsrk.so.
+
+Tensors must live on the GPU ("cuda" == ROCm/HIP device in PyTorch-ROCm) and be contiguous; every
+call is enqueued on the current torch stream.  Nothing here computes on the CPU: a CPU tensor or a
+missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import WinGeom, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libsrk operates on GPU tensors only (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("libsrk needs contiguous tensors")
+    return t.data_ptr()
+
+
+def _geom(H: int, W: int, shift: int):
+    return C.byref(WinGeom(H, W, shift))
+
+
+# ---------------------------------------------------------------------------------------------------
+# bit-exact index ops
+# ---------------------------------------------------------------------------------------------------
+def window_partition(x: torch.Tensor, window_size: int) -> torch.Tensor:
+    """reference window_partition (network_swinir.py:33-45): (B,H,W,C) -> (B*nW, ws, ws, C)."""
+    B, H, W, Cc = x.shape
+    x = x.contiguous()
+    out = torch.empty((B * (H // window_size) * (W // window_size), window_size, window_size, Cc), dtype=x.dtype, device=x.device)
+    check(lib().srk_window_partition(_p(x), _p(out), B, H, W, Cc, window_size, x.element_size(), _stream()))
+    return out
+
+
+def window_reverse(windows: torch.Tensor, window_size: int, H: int, W: int) -> torch.Tensor:
+    """reference window_reverse (network_swinir.py:48-62): (B*nW, ws, ws, C) -> (B,H,W,C)."""
+    B = int(windows.shape[0] / (H * W / window_size / window_size))
+    Cc = windows.shape[-1]
+    windows = windows.contiguous()
+    out = torch.empty((B, H, W, Cc), dtype=windows.dtype, device=windows.device)
+    check(lib().srk_window_reverse(_p(windows), _p(out), B, H, W, Cc, window_size, windows.element_size(), _stream()))
+    return out
+
+
+def roll2d(x: torch.Tensor, shifts: Tuple[int, int]) -> torch.Tensor:
+    """torch.roll(x, shifts, dims=(1, 2)) on (B,H,W,C)."""
+    B, H, W, Cc = x.shape
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib().srk_roll2d(_p(x), _p(out), B, H, W, Cc, int(shifts[0]), int(shifts[1]), x.element_size(), _stream()))
+    return out
+
+
+def pixel_shuffle(x: torch.Tensor, r: int) -> torch.Tensor:
+    B, Crr, H, W = x.shape
+    Cc = Crr // (r * r)
+    x = x.contiguous()
+    out = torch.empty((B, Cc, H * r, W * r), dtype=x.dtype, device=x.device)
+    check(lib().srk_pixel_shuffle(_p(x), _p(out), B, Cc, H, W, r, x.element_size(), _stream()))
+    return out
+
+
+def shift_mask(H: int, W: int, window_size: int, shift: int, device="cuda") -> torch.Tensor:
+    N = window_size * window_size
+    out = torch.empty(((H // window_size) * (W // window_size), N, N), dtype=torch.float32, device=device)
+    check(lib().srk_shift_mask(_p(out), H, W, window_size, shift, _stream()))
+    return out
+
+
+def relative_position_index(window_size: int, device="cuda") -> torch.Tensor:
+    N = window_size * window_size
+    out = torch.empty((N, N), dtype=torch.int64, device=device)
+    check(lib().srk_relative_position_index(_p(out), window_size, _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# building blocks in the kernels' internal (padded) layouts
+# ---------------------------------------------------------------------------------------------------
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, C_real: int, *, geom=None,
+                  out_bf16: bool = True, out_f32: bool = False):
+    """x fp32 [rows, CP] -> (y_bf16 | None, y_f32 | None, mean, rstd).  geom=(H, W, shift) -> window order."""
+    rows, CP = x.shape
+    yb = torch.empty((rows, CP), dtype=torch.bfloat16, device=x.device) if out_bf16 else None
+    yf = torch.empty((rows, CP), dtype=torch.float32, device=x.device) if out_f32 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    g = _geom(*geom) if geom is not None else None
+    check(lib().srk_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(yb), _p(yf), _p(mean), _p(rstd), rows, C_real, CP, g, _stream()))
+    return yb, yf, mean, rstd
+
+
+def window_attention_fwd(qkv: torch.Tensor, bias_dense: torch.Tensor, H: int, W: int, shift: int) -> torch.Tensor:
+    """qkv bf16 [3, B_, nH, 64, 32]; bias_dense fp32 [nH, 64, 64] -> out bf16 [B_*64, nH*32]."""
+    _, B_, nH, N, D = qkv.shape
+    assert N == 64 and D == 32
+    out = torch.empty((B_ * 64, nH * 32), dtype=torch.bfloat16, device=qkv.device)
+    check(lib().srk_window_attention_fwd(_p(qkv), _p(bias_dense), _p(out), B_, nH, _geom(H, W, shift), _stream()))
+    return out
+
+
+def window_attention_bwd(qkv: torch.Tensor, bias_dense: torch.Tensor, d_out: torch.Tensor, scale: float, H: int, W: int,
+                         shift: int):
+    """-> (d_qkv bf16 [B_*64, 3*nH*32], d_table fp32 [225, nH])."""
+    _, B_, nH, _, _ = qkv.shape
+    d_qkv = torch.empty((B_ * 64, 3 * nH * 32), dtype=torch.bfloat16, device=qkv.device)
+    d_table = torch.zeros((225, nH), dtype=torch.float32, device=qkv.device)
+    slab = torch.empty(lib().srk_window_attention_bwd_scratch(B_, nH), dtype=torch.uint8, device=qkv.device)
+    check(lib().srk_window_attention_bwd(_p(qkv), _p(bias_dense), _p(d_out), _p(d_qkv), _p(d_table), _p(slab), B_, nH,
+                                         float(scale), _geom(H, W, shift), _stream()))
+    return d_qkv, d_table
+
+
+def rel_pos_bias_expand(table: torch.Tensor) -> torch.Tensor:
+    nH = table.shape[1]
+    out = torch.empty((nH, 64, 64), dtype=torch.float32, device=table.device)
+    check(lib().srk_rel_pos_bias_expand(_p(table), _p(out), nH, _stream()))
+    return out
+
+
+def linear_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    M, K = a.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    check(lib().srk_linear_bf16(_p(a), _p(w), _p(bias), _p(y), M, N, K, _stream()))
+    return y
+
+
+def linear_wgrad_bf16(y: torch.Tensor, x: torch.Tensor, with_bias: bool = True):
+    M, N = y.shape
+    K = x.shape[1]
+    dw = torch.zeros((N, K), dtype=torch.float32, device=y.device)
+    db = torch.zeros((N,), dtype=torch.float32, device=y.device) if with_bias else None
+    check(lib().srk_linear_wgrad_bf16(_p(y), _p(x), _p(dw), _p(db), M, N, K, _stream()))
+    return dw, db
+
+
+def conv3x3_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x bf16 NHWC [B,H,W,CinP], w bf16 [N, 9*CinP] (tap-major) -> y bf16 NHWC [B,H,W,N]."""
+    B, H, W, CinP = x.shape
+    N = w.shape[0]
+    y = torch.empty((B, H, W, N), dtype=torch.bfloat16, device=x.device)
+    check(lib().srk_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(y), B, H, W, CinP, N, _stream()))
+    return y
+
+
+def conv3x3_wgrad_bf16(dy: torch.Tensor, x: torch.Tensor):
+    B, H, W, N = dy.shape
+    CinP = x.shape[-1]
+    dw = torch.zeros((N, 9 * CinP), dtype=torch.float32, device=x.device)
+    db = torch.zeros((N,), dtype=torch.float32, device=x.device)
+    check(lib().srk_conv3x3_wgrad_bf16(_p(dy), _p(x), _p(dw), _p(db), B, H, W, CinP, N, _stream()))
+    return dw, db
+
+
+def probe_trread(tile: torch.Tensor) -> torch.Tensor:
+    """tile int16 [64,16] -> fragments int16 [64 lanes, 8]; expected[l, j] = tile[8*(l>>4)+j, l&15]."""
+    out = torch.empty((64, 8), dtype=torch.int16, device=tile.device)
+    check(lib().srk_probe_trread(_p(tile), _p(out), _stream()))
+    return out
+
+
+def l1_loss_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
+    """-> (loss fp32 [1], d_pred | None, nonfinite int32 [1])   (finetune_swinir.py:66-67, :133-143)."""
+    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=pred.device)
+    d = torch.empty_like(pred) if want_grad else None
+    check(lib().srk_l1_loss_fwd_bwd(_p(pred), _p(target), _p(d), _p(loss), _p(bad), pred.numel(), float(grad_scale), _stream()))
+    return loss, d, bad
