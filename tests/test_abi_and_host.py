@@ -1,0 +1,82 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol include/srk.h declares, the
+plan bookkeeping (pure host code) matches the reference's parameter schema, and the product path
+fails loudly without a GPU."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import swinir_oracle as O
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tpu_superresolution_amd import build
+    build.build(verbose=False)
+    from tpu_superresolution_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = lib.declared_symbols()
+    assert len(names) >= 35
+    handle = lib.lib()
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, missing
+    undeclared = [n for n in lib._SIGNATURES if n not in names]
+    assert not undeclared, undeclared
+    assert b"gfx950" in handle.srk_version()
+
+
+@pytest.mark.parametrize("cfg", [O.SwinIRConfig.classical_x4(), O.SwinIRConfig.light_x2()])
+def test_plan_parameter_table_matches_reference_schema(lib, cfg):
+    from tpu_superresolution_amd.engine import SwinIRPlan
+    plan = SwinIRPlan(img_size=cfg.img_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depths=cfg.depths,
+                      num_heads=cfg.num_heads, window_size=cfg.window_size, mlp_ratio=cfg.mlp_ratio, upscale=cfg.upscale,
+                      img_range=cfg.img_range, upsampler=cfg.upsampler)
+    schema = [(k, tuple(s)) for k, s, kind in O.state_dict_schema(cfg) if kind == "param"]
+    assert [(p.name, p.shape) for p in plan.params] == schema
+    offs = [p.offset for p in plan.params]
+    assert all(o % 64 == 0 for o in offs) and offs == sorted(offs)
+    assert plan.param_floats >= sum(p.numel for p in plan.params)
+    # backward segments tile the flat buffer back to front
+    rs = plan.segment_ranges
+    assert rs[0][1] == plan.param_floats and rs[-1][0] == 0
+    assert all(rs[i][0] == rs[i + 1][1] for i in range(len(rs) - 1))
+    assert len(rs) == len(cfg.depths) + 2
+
+
+def test_module_state_dict_schema_and_loud_failure(lib):
+    import tpu_superresolution_amd as T
+    cfg = O.SwinIRConfig.light_x2()
+    m = T.SwinIR(**cfg.kwargs())
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s, _ in O.state_dict_schema(cfg)]
+    sd = O.random_state_dict(cfg, 1)
+    m.load_state_dict(sd, strict=True)
+    assert m.state_dict()["layers.0.residual_group.blocks.1.attn_mask"].shape == (64, 64, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 16, 16))
+    with pytest.raises(NotImplementedError):
+        m.layers[0].residual_group.blocks[0](torch.rand(1, 64, 60), (8, 8))
+
+
+def test_unsupported_configs_are_refused_by_the_c_api(lib):
+    from tpu_superresolution_amd.engine import SwinIRPlan
+    base = dict(img_size=64, in_chans=3, embed_dim=180, depths=[6] * 6, num_heads=[6] * 6, window_size=8, mlp_ratio=2, upscale=4,
+                img_range=1.0, upsampler="pixelshuffle")
+    with pytest.raises(NotImplementedError, match="window_size == 8"):
+        SwinIRPlan(**{**base, "window_size": 7})
+    with pytest.raises(NotImplementedError, match="head_dim <= 32"):
+        SwinIRPlan(**{**base, "num_heads": [3] * 6})
+    with pytest.raises(ValueError, match="scale 5 is not supported"):
+        SwinIRPlan(**{**base, "upscale": 5})
+    with pytest.raises(NotImplementedError):
+        SwinIRPlan(**{**base, "upsampler": "nearest+conv"})
+
+
+def test_index_entry_points_validate_arguments_without_a_gpu(lib):
+    h = lib.lib()
+    assert h.srk_window_partition(None, None, 1, 8, 8, 3, 8, 4, None) == -2
+    assert h.srk_shift_mask(C.c_void_p(16), 64, 64, 8, 8, None) == -1
+    assert b"shift_size must in 0-window_size" in h.srk_last_error()
+    assert h.srk_window_partition(C.c_void_p(16), C.c_void_p(16), 1, 13, 8, 3, 8, 4, None) == -1

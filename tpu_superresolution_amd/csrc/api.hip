@@ -23,6 +23,30 @@ int srk_check_launch(const char* what) {
   return SRK_OK;
 }
 
+// ---- timing probe ----------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct Probe {
+  int family = 0;
+  bool active = false;
+  size_t count = 0;
+  double flops = 0.0;
+  std::vector<hipEvent_t> ev0, ev1;
+} g_probe;
+}  // namespace
+
+void srk_probe_pre(int family, hipStream_t stream, double flops) {
+  if (!g_probe.active || family != g_probe.family || g_probe.count >= g_probe.ev0.size()) return;
+  hipEventRecord(g_probe.ev0[g_probe.count], stream);
+  g_probe.flops += flops;
+}
+
+void srk_probe_post(int family, hipStream_t stream) {
+  if (!g_probe.active || family != g_probe.family || g_probe.count >= g_probe.ev0.size()) return;
+  hipEventRecord(g_probe.ev1[g_probe.count], stream);
+  ++g_probe.count;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #define REQ_PTR(p) SRK_REQUIRE((p) != nullptr, SRK_E_NULL, "%s: null pointer '%s'", __func__, #p)
@@ -166,6 +190,43 @@ int srk_conv3x3_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, floa
 int srk_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, srk_stream_t stream) {
   REQ_PTR(x); REQ_PTR(y);
   return srk_launch_cast_f32_bf16(x, y, n, (hipStream_t)stream);
+}
+
+int srk_probe_begin(int family, int capacity) {
+  SRK_REQUIRE(!g_probe.active, SRK_E_STATE, "probe_begin: a probe is already active");
+  SRK_REQUIRE(family >= 1 && family <= 7 && capacity > 0 && capacity <= (1 << 20), SRK_E_SHAPE, "probe_begin: bad arguments");
+  while ((int)g_probe.ev0.size() < capacity) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      srk_set_error("probe_begin: hipEventCreate failed");
+      return SRK_E_LAUNCH;
+    }
+    g_probe.ev0.push_back(a);
+    g_probe.ev1.push_back(b);
+  }
+  g_probe.family = family;
+  g_probe.count = 0;
+  g_probe.flops = 0.0;
+  g_probe.active = true;
+  return SRK_OK;
+}
+
+int srk_probe_end(double* total_ms, double* flops, int* launches) {
+  SRK_REQUIRE(g_probe.active, SRK_E_STATE, "probe_end: no active probe");
+  g_probe.active = false;
+  double ms = 0.0;
+  for (size_t i = 0; i < g_probe.count; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_probe.ev1[i]) != hipSuccess || hipEventElapsedTime(&t, g_probe.ev0[i], g_probe.ev1[i]) != hipSuccess) {
+      srk_set_error("probe_end: event query failed");
+      return SRK_E_LAUNCH;
+    }
+    ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = g_probe.flops;
+  if (launches) *launches = (int)g_probe.count;
+  return SRK_OK;
 }
 
 int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream) {

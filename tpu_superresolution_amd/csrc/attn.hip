@@ -414,7 +414,9 @@ int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long 
                         hipStream_t stream) {
   const int wpw = B_ >= 4096 ? 4 : 1;
   dim3 grid((unsigned)((B_ + 4 * wpw - 1) / (4 * wpw)), nH);
+  srk_probe_pre(FAM_ATTN_FWD, stream, 0.0);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, qkv, biasd, ao, B_, nH, nH * 32, geom, wpw);
+  srk_probe_post(FAM_ATTN_FWD, stream);
   return srk_check_launch("attn_fwd");
 }
 
@@ -440,8 +442,10 @@ int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao
     configured = true;
   }
   dim3 grid(nslab / 4, nH);
+  srk_probe_pre(FAM_ATTN_BWD, stream, 0.0);
   hipLaunchKernelGGL(attn_bwd_kernel, grid, dim3(256), lds, stream, qkv, biasd, dao, dqkv, dbias_slab, B_, nH, nH * 32,
                      geom, wpw, scale);
+  srk_probe_post(FAM_ATTN_BWD, stream);
   int rc = srk_check_launch("attn_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(rpb_reduce_kernel, dim3(225, nH), dim3(64), 0, stream, dbias_slab, dtable, nslab, nH);

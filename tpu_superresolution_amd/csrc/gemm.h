@@ -43,6 +43,7 @@ struct GemmParams {
   bf16_t* outb2;
   const float* res;    // fp32 residual
   const bf16_t* aux;   // bf16 auxiliary (pre-activation / activation sign)
+  double flops;        // algorithmic (un-padded) FLOPs of this launch, for the timing probe
   int ldo;             // row stride (elements) of outf/outb/res/aux
   float scale;         // EP_QKV q scale; EP_LRELU/EP_DLRELU slope
   int nH, CA;          // EP_QKV: heads and nH*32

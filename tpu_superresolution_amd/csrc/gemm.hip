@@ -273,7 +273,10 @@ int launch(const GemmParams& p, hipStream_t stream) {
     configured = true;
   }
   dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN));
+  const int fam = LD == LD_ROWS ? FAM_GEMM_LINEAR : FAM_GEMM_CONV;
+  srk_probe_pre(fam, stream, p.flops);
   hipLaunchKernelGGL((gemm_kernel<LD, EP, NT, NARROW>), grid, dim3(256), lds, stream, p);
+  srk_probe_post(fam, stream);
   return srk_check_launch("gemm");
 }
 

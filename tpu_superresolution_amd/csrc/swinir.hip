@@ -344,6 +344,7 @@ int run_conv(const Ctx& c, const ConvW& cw, int loader, int ep, const bf16_t* in
   g.K = 9 * cw.CinP;
   g.B = B; g.H = H; g.W = W; g.CinP = cw.CinP;
   g.bias = c.side + cw.bc;
+  g.flops = 2.0 * g.M * cw.Cout * cw.Cin * 9;
   if (g.ldo == 0) g.ldo = cw.NP;
   return srk_launch_gemm(loader, ep, g, c.stream);
 }
@@ -569,6 +570,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
   const int T = (int)w.T;
   const int HW = H * W;
   hipStream_t st = c.stream;
+  const double fl_qkv = 2.0 * T * 3 * C * C, fl_proj = 2.0 * T * C * C, fl_mlp = 2.0 * T * (double)p->HID * C;
 
   RUN(srk_launch_img_prep(x, c.at<float>(w.img4), B, p->Cimg, H0, W0, H, W, p->cfg.img_range, p->cfg.mean, st));
   RUN(srk_launch_stem_conv(c.at<float>(w.img4), params + p->p_conv_first_w, params + p->p_conv_first_b, c.at<float>(w.f0), B, H,
@@ -592,6 +594,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.xn1w); g.lda = CP; g.Wt = c.packed + bw.Wqkv; g.M = T; g.N = 3 * bw.CA; g.K = CP;
         g.bias = c.side + bw.bqkv; g.outb = c.at<bf16_t>(ba.qkv); g.scale = bw.scale; g.nH = bw.nH; g.CA = bw.CA; g.B_ = T / 64;
+        g.flops = fl_qkv;
         RUN(srk_launch_gemm(LD_ROWS, EP_QKV, g, st));
       }
       // softmax(qk^T + bias + mask) v                :125-142
@@ -600,7 +603,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.ao); g.lda = bw.CA; g.Wt = c.packed + bw.Wproj; g.M = T; g.N = CP; g.K = bw.CA;
         g.bias = c.side + bw.bproj; g.res = c.at<float>(ba.x_in); g.outf = c.at<float>(ba.x1); g.ldo = CP; g.geom = geom;
-        g.rowscale = ds_attn; g.rows_per_sample = HW;
+        g.rowscale = ds_attn; g.rows_per_sample = HW; g.flops = fl_proj;
         RUN(srk_launch_gemm(LD_ROWS, EP_PROJ_RES, g, st));
       }
       // LN2                                          :277
@@ -609,7 +612,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
       {  // fc1 + GELU                                 :25-26
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.xn2); g.lda = CP; g.Wt = c.packed + bw.Wfc1; g.M = T; g.N = HP; g.K = CP;
-        g.bias = c.side + bw.bfc1; g.outb = c.at<bf16_t>(ba.u); g.outb2 = c.at<bf16_t>(ba.h); g.ldo = HP;
+        g.bias = c.side + bw.bfc1; g.outb = c.at<bf16_t>(ba.u); g.outb2 = c.at<bf16_t>(ba.h); g.ldo = HP; g.flops = fl_mlp;
         RUN(srk_launch_gemm(LD_ROWS, EP_GELU, g, st));
       }
       {  // fc2 + residual                             :28, :277
@@ -617,7 +620,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         g.A = c.at<bf16_t>(ba.h); g.lda = HP; g.Wt = c.packed + bw.Wfc2; g.M = T; g.N = CP; g.K = HP;
         g.bias = c.side + bw.bfc2; g.res = c.at<float>(ba.x1); g.outf = c.at<float>(ba.x_out); g.ldo = CP;
         g.outb = (j == depth - 1) ? c.at<bf16_t>(w.layer_xb[l]) : nullptr;
-        g.rowscale = ds_mlp; g.rows_per_sample = HW;
+        g.rowscale = ds_mlp; g.rows_per_sample = HW; g.flops = fl_mlp;
         RUN(srk_launch_gemm(LD_ROWS, EP_RES, g, st));
       }
     }
@@ -683,11 +686,14 @@ static int conv_wgrad(const Ctx& c, const ConvW& cw, const bf16_t* Y, const bf16
   q.Y = Y; q.ldy = cw.NP; q.X = X; q.ldx = cw.CinP; q.M = B * H * W; q.N = cw.NP; q.K = cw.CinP;
   q.dW = c.at<float>(c.p->ws.gstage_w) + cw.Wc; q.ldw = 9 * cw.CinP; q.db = c.at<float>(c.p->ws.gstage_side) + cw.bc;
   q.conv = 1; q.B = B; q.H = H; q.W = W; q.r = r; q.Cs = 64;
+  q.flops = 2.0 * q.M * cw.Cout * cw.Cin * 9;
   return srk_launch_wgrad(q, c.stream);
 }
 
-static int lin_wgrad(const Ctx& c, const bf16_t* Y, int N, const bf16_t* X, int K, int M, long long Woff, long long boff) {
+static int lin_wgrad(const Ctx& c, const bf16_t* Y, int N, const bf16_t* X, int K, int M, long long Woff, long long boff,
+                     double flops) {
   WgradParams q = {};
+  q.flops = flops;
   q.Y = Y; q.ldy = N; q.X = X; q.ldx = K; q.M = M; q.N = N; q.K = K;
   q.dW = c.at<float>(c.p->ws.gstage_w) + Woff; q.ldw = K; q.db = c.at<float>(c.p->ws.gstage_side) + boff;
   return srk_launch_wgrad(q, c.stream);
@@ -709,6 +715,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
   const int T = (int)w.T, HW = H * W;
   hipStream_t st = c.stream;
   const int s = p->cfg.upscale;
+  const double fl_qkv = 2.0 * T * 3 * C * C, fl_proj = 2.0 * T * C * C, fl_mlp = 2.0 * T * (double)p->HID * C;
   float* gstage_w = c.at<float>(w.gstage_w);
   float* gstage_side = c.at<float>(w.gstage_side);
 
@@ -739,6 +746,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gup[k]); g.Wt = c.packed + cw.WcT; g.M = B * hs * wsz; g.N = 64; g.K = 9 * cw.NP;
           g.B = B; g.H = hs; g.W = wsz; g.CinP = cw.NP; g.r = p->stage_r; g.Cs = 64; g.ldo = 64;
+          g.flops = 2.0 * g.M * cw.Cout * cw.Cin * 9;
           if (k == 0) {
             g.outb = c.at<bf16_t>(w.gt1); g.aux = c.at<bf16_t>(w.t1); g.scale = 0.01f;
             RUN(srk_launch_gemm(LD_CONV3_PS, EP_DLRELU, g, st));
@@ -751,7 +759,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         RUN(conv_wgrad(c, cb, c.at<bf16_t>(w.gt1), c.at<bf16_t>(w.fb), B, H, W, 1));
         GemmParams g = {};
         g.A = c.at<bf16_t>(w.gt1); g.Wt = c.packed + cb.WcT; g.M = T; g.N = CP; g.K = 9 * 64; g.B = B; g.H = H; g.W = W; g.CinP = 64;
-        g.outb = c.at<bf16_t>(w.gfb); g.ldo = CP;
+        g.outb = c.at<bf16_t>(w.gfb); g.ldo = CP; g.flops = 2.0 * T * cb.Cout * cb.Cin * 9;
         RUN(srk_launch_gemm(LD_CONV3, EP_BF16, g, st));
       } else {
         const ConvW& cu = p->up_direct;
@@ -766,7 +774,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
       {
         GemmParams g = {};
         g.A = c.at<bf16_t>(w.gfb); g.Wt = c.packed + ca.WcT; g.M = T; g.N = CP; g.K = 9 * CP; g.B = B; g.H = H; g.W = W; g.CinP = CP;
-        g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP;
+        g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP; g.flops = 2.0 * T * ca.Cout * ca.Cin * 9;
         RUN(srk_launch_gemm(LD_CONV3, EP_BF16, g, st));
       }
       // final norm
@@ -786,6 +794,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         g.A = c.at<bf16_t>(w.gxb); g.Wt = c.packed + cw.WcT; g.M = T; g.N = CP; g.K = 9 * CP; g.B = B; g.H = H; g.W = W; g.CinP = CP;
         g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxb2); g.ldo = CP;
         g.rowscale = drop_scale ? drop_scale + ((size_t)last * 2 + 1) * B : nullptr; g.rows_per_sample = HW;
+        g.flops = 2.0 * T * cw.Cout * cw.Cin * 9;
         RUN(srk_launch_gemm(LD_CONV3, EP_F32_BF16, g, st));
       }
       for (int j = depth - 1; j >= 0; --j) {
@@ -798,17 +807,17 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         {  // d h = d x2 . Wfc2 ; d u = d h * gelu'(u)
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gxb2); g.lda = CP; g.Wt = c.packed + bw.Wfc2T; g.M = T; g.N = HP; g.K = CP;
-          g.outb = c.at<bf16_t>(w.du); g.aux = c.at<bf16_t>(ba.u); g.ldo = HP;
+          g.outb = c.at<bf16_t>(w.du); g.aux = c.at<bf16_t>(ba.u); g.ldo = HP; g.flops = fl_mlp;
           RUN(srk_launch_gemm(LD_ROWS, EP_DGELU, g, st));
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.gxb2), CP, c.at<bf16_t>(ba.h), HP, T, bw.Wfc2, bw.bfc2));
+        RUN(lin_wgrad(c, c.at<bf16_t>(w.gxb2), CP, c.at<bf16_t>(ba.h), HP, T, bw.Wfc2, bw.bfc2, fl_mlp));
         {  // d xn2 = d u . Wfc1
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.du); g.lda = HP; g.Wt = c.packed + bw.Wfc1T; g.M = T; g.N = CP; g.K = HP;
-          g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP;
+          g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP; g.flops = fl_mlp;
           RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.du), HP, c.at<bf16_t>(ba.xn2), CP, T, bw.Wfc1, bw.bfc1));
+        RUN(lin_wgrad(c, c.at<bf16_t>(w.du), HP, c.at<bf16_t>(ba.xn2), CP, T, bw.Wfc1, bw.bfc1, fl_mlp));
         // LN2 backward, iterated in window order; emits the (DropPath-scaled) bf16 gradient of x1 in window order
         RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x1), c.at<float>(ba.mean2), c.at<float>(ba.rstd2), params + bw.n2w,
                               c.at<float>(w.gx2), c.at<bf16_t>(w.gxbw), grads + bw.n2w, grads + bw.n2b, T, C, CP, &geom, 0, 0, 1, 1,
@@ -816,19 +825,19 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         {  // d attn_out = d x1(window order) . Wproj
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gxbw); g.lda = CP; g.Wt = c.packed + bw.WprojT; g.M = T; g.N = bw.CA; g.K = CP;
-          g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA;
+          g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA; g.flops = fl_proj;
           RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj));
+        RUN(lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj, fl_proj));
         RUN(srk_launch_attn_bwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(w.dao), c.at<bf16_t>(w.dqkv),
                                 c.at<float>(w.slab), grads + bw.rpb, T / 64, bw.nH, geom, bw.scale, st));
         {  // d xn1 (window order) = d qkv . Wqkv
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.dqkv); g.lda = 3 * bw.CA; g.Wt = c.packed + bw.WqkvT; g.M = T; g.N = CP; g.K = 3 * bw.CA;
-          g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP;
+          g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP; g.flops = fl_qkv;
           RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.dqkv), 3 * bw.CA, c.at<bf16_t>(ba.xn1w), CP, T, bw.Wqkv, bw.bqkv));
+        RUN(lin_wgrad(c, c.at<bf16_t>(w.dqkv), 3 * bw.CA, c.at<bf16_t>(ba.xn1w), CP, T, bw.Wqkv, bw.bqkv, fl_qkv));
         // LN1 backward (+ window reverse + un-roll); emits the bf16 gradient for the previous block's MLP branch
         RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x_in), c.at<float>(ba.mean1), c.at<float>(ba.rstd1),
                               params + bw.n1w, c.at<float>(w.gx2), c.at<bf16_t>(w.gxb2), grads + bw.n1w, grads + bw.n1b, T, C, CP,

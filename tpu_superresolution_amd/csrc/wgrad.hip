@@ -187,7 +187,10 @@ int launch(const WgradParams& p, hipStream_t stream) {
   if (m_per < 256) m_per = 256;
   q.m_per = m_per;
   splits = cdiv(p.M, m_per);
+  const int fam = CONV ? FAM_WGRAD_CONV : FAM_WGRAD_LINEAR;
+  srk_probe_pre(fam, stream, p.flops);
   hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles, splits), dim3(256), lds, stream, q);
+  srk_probe_post(fam, stream);
   return srk_check_launch("wgrad");
 }
 

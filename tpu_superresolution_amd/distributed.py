@@ -1,0 +1,140 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference has no distributed code; this is the MI355X-side design for BASELINE cfg3 (LR/HR
+patch batches sharded across ranks, gradients summed).  SwinIR has no cross-sample
+operator (LayerNorm only), so pure data parallelism is exact.
+
+The C backward runs in segments (tail, RSTB L-1 .. RSTB 0, head); the parameters -- and therefore
+the gradients -- of a segment are one contiguous slice of the flat fp32 gradient buffer.  As soon as
+a segment has been enqueued on the compute stream, its slice is all-reduced on a side HIP stream
+(event-ordered after the segment), so the collective of segment s overlaps the backward kernels of
+segment s+1.  ``finish()`` joins the side stream before the optimizer reads the gradients (the global
+norm must see the reduced gradients).  Gradients are summed; the division by world size is folded
+into the fused optimizer (``FusedAdamW.grad_div``).
+
+``GradSynchronizer`` is device-agnostic (CPU tensors + gloo work too) so that the bucket arithmetic
+and the collective pattern are covered by world_size-2 CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  backend 'nccl' is RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [begin, end) of n samples for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def merge_buckets(ranges: Sequence[Tuple[int, int]], min_elems: int) -> List[Tuple[int, int, int]]:
+    """Group consecutive backward segments (in execution order; each a contiguous slice, slices descending
+    in address) into buckets of at least `min_elems` elements.  Returns (last_segment_index, begin, end)."""
+    out: List[Tuple[int, int, int]] = []
+    cur_b = cur_e = None
+    prev_b = None
+    for i, (b, e) in enumerate(ranges):
+        if prev_b is not None and e != prev_b:
+            raise ValueError("segments are not contiguous/descending")
+        prev_b = b
+        if cur_b is None:
+            cur_b, cur_e = b, e
+        else:
+            cur_b = b
+        if cur_e - cur_b >= min_elems or i == len(ranges) - 1:
+            out.append((i, cur_b, cur_e))
+            cur_b = cur_e = None
+    return out
+
+
+class GradSynchronizer:
+    """Bucketed, overlapped sum-all-reduce of a flat gradient buffer."""
+
+    def __init__(self, segment_ranges: Sequence[Tuple[int, int]], min_bucket_elems: int = 1 << 20,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.buckets = merge_buckets(segment_ranges, min_bucket_elems)
+        self._by_last = {last: (b, e) for last, b, e in self.buckets}
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._side: Optional[torch.cuda.Stream] = None
+        self._works = []
+        self._flat: Optional[torch.Tensor] = None
+
+    def bind(self, flat_grad: torch.Tensor) -> None:
+        self._flat = flat_grad
+        if flat_grad.is_cuda and self._side is None:
+            self._side = torch.cuda.Stream(device=flat_grad.device)
+
+    def segment_done(self, seg: int, begin: int = 0, end: int = 0) -> None:
+        """Call right after backward segment `seg` has been enqueued on the current stream."""
+        if self.world == 1 or seg not in self._by_last:
+            return
+        b, e = self._by_last[seg]
+        chunk = self._flat[b:e]
+        if chunk.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        """Make the current stream wait for every outstanding bucket."""
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+
+class DataParallelSwinIR:
+    """Wraps a SwinIR: identical initial weights on every rank, overlapped gradient all-reduce.
+
+        model = SwinIR(...).cuda(); dp = DataParallelSwinIR(model); opt = FusedAdamW(model, grad_div=dp.world)
+        out = model(lr_shard); loss.backward(); dp.finish(); opt.step()
+    """
+
+    def __init__(self, model, min_bucket_elems: int = 1 << 20, group: Optional[dist.ProcessGroup] = None):
+        self.model = model
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._sync: Optional[GradSynchronizer] = None
+        self._min_bucket = min_bucket_elems
+
+    def attach(self, device: torch.device) -> None:
+        eng = self.model._bind(device)
+        if self.world > 1:
+            dist.broadcast(eng.flat, src=0, group=self.group)       # same weights on every rank
+            eng.packed_valid = False
+        self._sync = GradSynchronizer(eng.plan.segment_ranges, self._min_bucket, self.group)
+        self._sync.bind(eng.ensure_grad())
+        eng.segment_hook = self._sync.segment_done
+
+    def finish(self) -> None:
+        if self._sync is not None:
+            self._sync.finish()
