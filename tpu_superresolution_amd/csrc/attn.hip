@@ -61,15 +61,27 @@ __device__ __forceinline__ float xsum4(float v) {
 }
 
 // scores^T + bias + mask -> probabilities^T (in place), T-layout: s[jt][it][e] = S[i=16it+r16][j=16jt+4g+e]
-__device__ __forceinline__ void softmax_T(f32x4_t (&s)[4][4], const f32x4_t (&bias)[4][4], const WinGeom& geom,
-                                          int w, int lane) {
+struct BiasRegs {   // dense bias of one head held in 64 VGPRs (forward: reused across the windows of a wave)
+  f32x4_t v[4][4];
+  __device__ __forceinline__ f32x4_t get(int jt, int it, int, int) const { return v[jt][it]; }
+};
+struct BiasMem {    // re-read from L2 per window (backward: registers are needed for d(bias))
+  const float* base;  // biasd + h*4096
+  __device__ __forceinline__ f32x4_t get(int jt, int it, int r16, int g) const {
+    const float4 b = *reinterpret_cast<const float4*>(base + (16 * it + r16) * 64 + 16 * jt + 4 * g);
+    return f32x4_t{b.x, b.y, b.z, b.w};
+  }
+};
+
+template <typename Bias>
+__device__ __forceinline__ void softmax_T(f32x4_t (&s)[4][4], const Bias& bias, const WinGeom& geom, int w, int lane) {
   const int r16 = lane & 15, g = lane >> 4;
   const int wy = w / geom.nWw, wx = w - wy * geom.nWw;
   const bool masked = geom.shift > 0 && (wy == geom.H / 8 - 1 || wx == geom.nWw - 1);
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) s[jt][it] += bias[jt][it];
+    for (int it = 0; it < 4; ++it) s[jt][it] += bias.get(jt, it, r16, g);
   if (masked) {
     int labi[4];
 #pragma unroll
@@ -110,7 +122,7 @@ __device__ __forceinline__ void softmax_T(f32x4_t (&s)[4][4], const f32x4_t (&bi
   }
 }
 
-__device__ __forceinline__ void load_bias_T(f32x4_t (&bias)[4][4], const float* biasd, int h, int lane) {
+__device__ __forceinline__ void load_bias_T(f32x4_t (&bias)[4][4], const float* biasd, int h, int lane) {  // -> BiasRegs::v
   const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
@@ -134,8 +146,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   bf16_t* Vs = lds[wave];
   const long long w_begin = ((long long)blockIdx.x * 4 + wave) * wpw;
 
-  f32x4_t bias[4][4];
-  load_bias_T(bias, biasd, h, lane);
+  BiasRegs bias;
+  load_bias_T(bias.v, biasd, h, lane);
 
   for (int wi = 0; wi < wpw; ++wi) {
     const long long b_ = w_begin + wi;
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   const long long w_begin = slab_id * wpw;
   const int ldq = 3 * CA;
 
-  f32x4_t bias[4][4], dbias[4][4];
-  load_bias_T(bias, biasd, h, lane);
+  const BiasMem bias = {biasd + h * 4096};
+  f32x4_t dbias[4][4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -383,20 +395,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
 }
 
 // d(table)[t][h] += sum over slabs and over (i,j) with rpi(i,j) == t.  One workgroup per (t, h).
-__global__ __launch_bounds__(64) void rpb_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dtable,
-                                                        int nslab, int nH) {
-  const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  // rpi(p,q) = (yp-yq+7)*15 + (xp-xq+7)  ->  dy = t/15 - 7, dx = t%15 - 7
-  const int dy = t / 15 - 7, dx = t % 15 - 7;
-  const int yi = lane >> 3, xi = lane & 7;      // lane = query token i
-  const int yj = yi - dy, xj = xi - dx;
+// One workgroup per (query token i, head h): the 4 waves sum row i of every slab (256-B coalesced reads, lane = key
+// token j), combine through LDS, and scatter the 64 row sums into the table with rpi(i, j).
+__global__ __launch_bounds__(256) void rpb_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dtable,
+                                                         int nslab, int nH) {
+  __shared__ float part[4][64];
+  const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.f;
-  if ((unsigned)yj < 8u && (unsigned)xj < 8u) {
-    const int j = yj * 8 + xj;
-    for (int sidx = 0; sidx < nslab; ++sidx) acc += slab[(((long long)sidx * nH + h) * 64 + lane) * 64 + j];
+  for (int sidx = wave; sidx < nslab; sidx += 4) acc += slab[(((long long)sidx * nH + h) * 64 + i) * 64 + lane];
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    // rpi(i,j) = (yi-yj+7)*15 + (xi-xj+7)
+    const int t = ((i >> 3) - (lane >> 3) + 7) * 15 + ((i & 7) - (lane & 7) + 7);
+    atomicAdd(dtable + t * nH + h, v);
   }
-  acc = wave_sum64(acc);
-  if (lane == 0) dtable[t * nH + h] += acc;
 }
 
 // dense bias[h][i][j] = table[rpi(i,j)][h]   (network_swinir.py:127-129)
@@ -448,7 +462,7 @@ int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao
   srk_probe_post(FAM_ATTN_BWD, stream);
   int rc = srk_check_launch("attn_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(rpb_reduce_kernel, dim3(225, nH), dim3(64), 0, stream, dbias_slab, dtable, nslab, nH);
+  hipLaunchKernelGGL(rpb_reduce_kernel, dim3(64, nH), dim3(256), 0, stream, dbias_slab, dtable, nslab, nH);
   return srk_check_launch("rpb_reduce");
 }
 

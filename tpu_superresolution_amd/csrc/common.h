@@ -56,9 +56,21 @@ __device__ __forceinline__ void unpack_bf2(unsigned u, float& lo, float& hi) {
 }
 
 // exact (erf) GELU and its derivative -- nn.GELU default (network_swinir.py:15, Mlp act_layer)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below fp32 rounding of the GELU result that is
+// then stored as bf16): ~14 VALU instructions instead of libm erff's ~40 -- the GELU epilogues are VALU-heavy.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
@@ -82,6 +94,17 @@ __device__ __forceinline__ int win_row_to_token(const WinGeom& g, int m) {
   if (y >= g.H) y -= g.H;
   if (x >= g.W) x -= g.W;
   return (b * g.H + y) * g.W + x;
+}
+
+// inverse of win_row_to_token: raster token -> window-order row
+__device__ __forceinline__ int token_to_win_row(const WinGeom& g, int t) {
+  const int hw = g.H * g.W;
+  const int b = t / hw, rem = t - b * hw;
+  int y = rem / g.W - g.shift, x = rem % g.W - g.shift;
+  if (y < 0) y += g.H;
+  if (x < 0) x += g.W;
+  const int w = (y >> 3) * g.nWw + (x >> 3);
+  return ((b * g.nW + w) << 6) | ((y & 7) << 3) | (x & 7);
 }
 
 // region label (0..8) of token p of window w in the shifted frame (network_swinir.py:219-230), ws 8 shift 4

@@ -25,6 +25,10 @@ enum SrkEpilogue {
   EP_RES_BF16 = 10,  // outb[m][n] = bf16(res[m][n] + v)
   EP_DLRELU = 11,    // outb = bf16(v * (aux[m][n] > 0 ? 1 : slope))     (no bias)
   EP_F32_BF16 = 12,  // outf[m][n] = v ; outb[m][n] = bf16(v)             (no bias unless given)
+  EP_LNBWD = 13,     // acc = dL/d(LN output) for a whole row (needs N == one tile): LayerNorm backward fused in.
+                     //   t = ln_rows_window ? token(geom, m) : m ; stats at (ln_stats_by_m ? m : t)
+                     //   dx = rstd*(dy*g - mean_c(dy*g) - xhat*mean_c(dy*g*xhat)) ; outf[t] += dx (gradient stream)
+                     //   outb[ln_out_window ? winrow(geom, t) : t] = bf16(outf[t] * rowscale[sample]) ; dgamma/dbeta atomics
 };
 
 struct GemmParams {
@@ -54,6 +58,15 @@ struct GemmParams {
   long long B_;        // EP_QKV: number of windows
   const float* rowscale;  // per-sample DropPath factor (EP_PROJ_RES / EP_RES: scales v; EP_F32_BF16: scales the bf16 copy)
   int rows_per_sample;    // tokens per sample for rowscale indexing
+  // EP_LNBWD
+  const float* ln_x;      // fp32 LN input [T][ldo]
+  const float* ln_mean;
+  const float* ln_rstd;
+  const float* ln_gamma;  // [C] (un-padded parameter)
+  float* ln_dgamma;       // [C] accumulated
+  float* ln_dbeta;
+  int ln_C;               // real channel count
+  int ln_rows_window, ln_stats_by_m, ln_out_window;
 };
 
 int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t stream);

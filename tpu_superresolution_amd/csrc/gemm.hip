@@ -11,6 +11,7 @@
 // conflict-free.  The MFMA is issued as D^T = Wt . A^T so that each lane ends up with four
 // consecutive n for one m: epilogues then store 8 B (bf16) / 16 B (fp32) per lane.
 #include "gemm.h"
+#include "gemm_rowep.h"
 
 namespace {
 
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
     if (kc + 1 < nk) store_stage(buf ^ 1);
     __syncthreads();
+  }
+
+  // ---- row-major epilogue through LDS (everything except the narrow image heads) ----------------
+  if constexpr (!NARROW) {
+    gemm_epilogue_rows<EP, NTT>(p, acc, smem, m0, n0, tid);
+    return;
   }
 
   // ---- epilogue: lane holds D[n = nb + 4g + e][m = mb + r16], e = 0..3 ----------------------------
@@ -310,6 +317,12 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
   CASE(LD_ROWS, EP_GELU)
   CASE(LD_ROWS, EP_RES)
   CASE(LD_ROWS, EP_DGELU)
+  if (loader == LD_ROWS && epilogue == EP_LNBWD) {
+    SRK_REQUIRE(p.N == 64 || p.N == 128 || p.N == 192, SRK_E_SHAPE, "gemm(ln-bwd epilogue): N=%d must be one tile (64/128/192)", p.N);
+    SRK_REQUIRE(p.ln_x && p.ln_mean && p.ln_rstd && p.ln_gamma && p.ln_dgamma && p.ln_dbeta && p.outf, SRK_E_NULL,
+                "gemm(ln-bwd epilogue): null pointer");
+    return dispatch_nt<LD_ROWS, EP_LNBWD>(p, stream);
+  }
   CASE(LD_CONV3, EP_RES)
   CASE(LD_CONV3, EP_RES_BF16)
   CASE(LD_CONV3, EP_LRELU)

@@ -389,51 +389,72 @@ __global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float* __res
   }
 }
 
-// dW[co][ci][tap] += sum_q X[q][ci] * gy[q - off(tap)][co];  db[co] += sum gy.  blockDim = CinP threads.
-__global__ void smallconv_wgrad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dW,
-                                       float* __restrict__ db, int B, int H, int W, int Cin, int CinP, int Co, int CoP,
-                                       int pix_per_block) {
-  extern __shared__ float gl[];         // [64 pixels][9][CoP]
+// dW[co][ci][tap] += sum_q X[q][ci] * gy[q - off(tap)][co];  db[co] += sum gy.
+// blockDim = CinP * PG: thread = (input channel ci, pixel group pg); a workgroup walks `pix_per_block` pixels in
+// chunks of 64 whose 3x3 gy neighbourhoods are staged in LDS; each thread keeps 9*COP partial sums in registers,
+// the PG groups are combined through LDS and one atomic per (co, ci, tap) per workgroup goes to memory.
+template <int COP>
+__global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gy,
+                                                              float* __restrict__ dW, float* __restrict__ db, int B, int H,
+                                                              int W, int Cin, int CinP, int Co, int pix_per_block) {
+  extern __shared__ float gl[];         // [64 pixels][9][COP], later reused as [PG][9*COP][CinP] for the reduction
   const long long npix = (long long)B * H * W;
   const long long p_begin = (long long)blockIdx.x * pix_per_block;
   const long long p_end = p_begin + pix_per_block < npix ? p_begin + pix_per_block : npix;
-  const int ci = threadIdx.x;
-  constexpr int MAXACC = 9 * 16;
-  float acc[MAXACC];
+  const int ci = threadIdx.x % CinP, pg = threadIdx.x / CinP, PG = blockDim.x / CinP;
+  float acc[9 * COP];
 #pragma unroll
-  for (int i = 0; i < MAXACC; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 9 * COP; ++i) acc[i] = 0.f;
   float accb = 0.f;
   for (long long pb = p_begin; pb < p_end; pb += 64) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 9 * CoP; i += blockDim.x) {
-      const int n = i % CoP, tap = (i / CoP) % 9, pp = i / (9 * CoP);
+    for (int i = threadIdx.x; i < 64 * 9 * COP; i += blockDim.x) {
+      const int n = i % COP, tap = (i / COP) % 9, pp = i / (9 * COP);
       const long long pix = pb + pp;
       float v = 0.f;
       if (pix < p_end) {
         const int xx = (int)(pix % W), y = (int)((pix / W) % H);
         const long long b = pix / ((long long)W * H);
         const int yy = y - (tap / 3 - 1), xs = xx - (tap % 3 - 1);
-        if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) v = gy[((b * H + yy) * W + xs) * CoP + n];
+        if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) v = gy[((b * H + yy) * W + xs) * COP + n];
       }
       gl[i] = v;
     }
     __syncthreads();
     const int cnt = (int)(p_end - pb < 64 ? p_end - pb : 64);
-    for (int pp = 0; pp < cnt; ++pp) {
-      const float xv = bf2f(x[(pb + pp) * CinP + ci]);
-      if (ci < Co) accb += gl[(pp * 9 + 4) * CoP + ci];   // centre tap == gy at this pixel
+    for (int pp0 = pg; pp0 < cnt; pp0 += 4 * PG) {
+      float xv[4];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
+      for (int u = 0; u < 4; ++u) {
+        const int pp = pp0 + u * PG;
+        xv[u] = pp < cnt ? bf2f(x[(pb + pp) * CinP + ci]) : 0.f;
+      }
 #pragma unroll
-        for (int co = 0; co < 16; ++co)
-          if (co < Co) acc[tap * 16 + co] += xv * gl[(pp * 9 + tap) * CoP + co];
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = pp0 + u * PG < cnt;
+        const int pp = ok ? pp0 + u * PG : 0;     // xv == 0 for the clamped ones
+        const float* gp = gl + pp * 9 * COP;
+        if (ok) accb += gp[4 * COP + (ci < COP ? ci : 0)];   // centre tap == gy at this pixel
+#pragma unroll
+        for (int t = 0; t < 9 * COP; t += 4) {
+          const float4 gv = *reinterpret_cast<const float4*>(gp + t);
+          acc[t] += xv[u] * gv.x; acc[t + 1] += xv[u] * gv.y; acc[t + 2] += xv[u] * gv.z; acc[t + 3] += xv[u] * gv.w;
+        }
+      }
     }
   }
-  if (ci < Cin) {
-    for (int tap = 0; tap < 9; ++tap)
-      for (int co = 0; co < Co; ++co) atomicAdd(dW + ((co * Cin) + ci) * 9 + tap, acc[tap * 16 + co]);
-  }
   if (ci < Co) atomicAdd(db + ci, accb);
+  __syncthreads();
+  for (int t = 0; t < 9 * COP; ++t) gl[(pg * 9 * COP + t) * CinP + ci] = acc[t];
+  __syncthreads();
+  if (pg == 0 && ci < Cin) {
+    for (int tap = 0; tap < 9; ++tap)
+      for (int co = 0; co < Co; ++co) {
+        float v = 0.f;
+        for (int q = 0; q < PG; ++q) v += gl[(q * 9 * COP + tap * COP + co) * CinP + ci];
+        atomicAdd(dW + ((co * Cin) + ci) * 9 + tap, v);
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -668,12 +689,29 @@ int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, in
 
 int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin,
                                int CinP, int Co, int CoP, hipStream_t stream) {
-  SRK_REQUIRE(Co <= 16 && CinP <= 1024 && CinP % 64 == 0, SRK_E_SHAPE, "smallconv wgrad: Co=%d CinP=%d", Co, CinP);
-  const size_t lds = (size_t)64 * 9 * CoP * sizeof(float);
+  SRK_REQUIRE(Co <= CoP && (CoP == 4 || CoP == 16) && CinP <= 256 && CinP % 64 == 0, SRK_E_SHAPE,
+              "smallconv wgrad: Co=%d CoP=%d CinP=%d", Co, CoP, CinP);
+  const int PG = 256 / CinP;
+  const int threads = CinP * PG;
+  const size_t stage = (size_t)64 * 9 * CoP, red = (size_t)PG * 9 * CoP * CinP;
+  const size_t lds = (stage > red ? stage : red) * sizeof(float);
   const long long npix = (long long)B * H * W;
-  const int ppb = 1024;
-  hipLaunchKernelGGL(smallconv_wgrad_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(CinP), lds, stream, x, gy, dW,
-                     db, B, H, W, Cin, CinP, Co, CoP, ppb);
+  const int ppb = 4096;
+  const unsigned grid = (unsigned)((npix + ppb - 1) / ppb);
+  if (CoP == 4) {
+    hipLaunchKernelGGL(smallconv_wgrad_kernel<4>, dim3(grid), dim3(threads), lds, stream, x, gy, dW, db, B, H, W, Cin, CinP, Co, ppb);
+  } else {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_wgrad_kernel<16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        srk_set_error("smallconv wgrad: cannot reserve LDS");
+        return SRK_E_LAUNCH;
+      }
+      configured = true;
+    }
+    hipLaunchKernelGGL(smallconv_wgrad_kernel<16>, dim3(grid), dim3(threads), lds, stream, x, gy, dW, db, B, H, W, Cin, CinP, Co, ppb);
+  }
   return srk_check_launch("smallconv_wgrad");
 }
 

@@ -690,13 +690,13 @@ static int conv_wgrad(const Ctx& c, const ConvW& cw, const bf16_t* Y, const bf16
   return srk_launch_wgrad(q, c.stream);
 }
 
-static int lin_wgrad(const Ctx& c, const bf16_t* Y, int N, const bf16_t* X, int K, int M, long long Woff, long long boff,
-                     double flops) {
+static WgradParams lin_wgrad(const Ctx& c, const bf16_t* Y, int N, const bf16_t* X, int K, int M, long long Woff, long long boff,
+                             double flops) {
   WgradParams q = {};
   q.flops = flops;
   q.Y = Y; q.ldy = N; q.X = X; q.ldx = K; q.M = M; q.N = N; q.K = K;
   q.dW = c.at<float>(c.p->ws.gstage_w) + Woff; q.ldw = K; q.db = c.at<float>(c.p->ws.gstage_side) + boff;
-  return srk_launch_wgrad(q, c.stream);
+  return q;
 }
 
 int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* packed, float* grads, const float* d_y,
@@ -716,6 +716,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
   hipStream_t st = c.stream;
   const int s = p->cfg.upscale;
   const double fl_qkv = 2.0 * T * 3 * C * C, fl_proj = 2.0 * T * C * C, fl_mlp = 2.0 * T * (double)p->HID * C;
+  const bool fuse_ln = CP == 64 || CP == 128 || CP == 192;   // LayerNorm backward inside the dgrad GEMM epilogue (row = one tile)
   float* gstage_w = c.at<float>(w.gstage_w);
   float* gstage_side = c.at<float>(w.gstage_side);
 
@@ -810,38 +811,60 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           g.outb = c.at<bf16_t>(w.du); g.aux = c.at<bf16_t>(ba.u); g.ldo = HP; g.flops = fl_mlp;
           RUN(srk_launch_gemm(LD_ROWS, EP_DGELU, g, st));
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.gxb2), CP, c.at<bf16_t>(ba.h), HP, T, bw.Wfc2, bw.bfc2, fl_mlp));
+        WgradParams wq[4];   // the four weight gradients of the block go out as one launch (before gxb2 is overwritten)
+        wq[0] = lin_wgrad(c, c.at<bf16_t>(w.gxb2), CP, c.at<bf16_t>(ba.h), HP, T, bw.Wfc2, bw.bfc2, fl_mlp);
         {  // d xn2 = d u . Wfc1
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.du); g.lda = HP; g.Wt = c.packed + bw.Wfc1T; g.M = T; g.N = CP; g.K = HP;
-          g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP; g.flops = fl_mlp;
-          RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
+          g.ldo = CP; g.flops = fl_mlp;
+          if (fuse_ln) {   // ... with LN2 backward fused into the epilogue: gx2 += dx1, gxbw = bf16(gx2 * f_attn) in window order
+            g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxbw); g.geom = geom; g.rowscale = ds_attn; g.rows_per_sample = HW;
+            g.ln_x = c.at<float>(ba.x1); g.ln_mean = c.at<float>(ba.mean2); g.ln_rstd = c.at<float>(ba.rstd2);
+            g.ln_gamma = params + bw.n2w; g.ln_dgamma = grads + bw.n2w; g.ln_dbeta = grads + bw.n2b; g.ln_C = C;
+            g.ln_rows_window = 0; g.ln_stats_by_m = 0; g.ln_out_window = 1;
+            RUN(srk_launch_gemm(LD_ROWS, EP_LNBWD, g, st));
+          } else {
+            g.outb = c.at<bf16_t>(w.dxn);
+            RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
+          }
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.du), HP, c.at<bf16_t>(ba.xn2), CP, T, bw.Wfc1, bw.bfc1, fl_mlp));
-        // LN2 backward, iterated in window order; emits the (DropPath-scaled) bf16 gradient of x1 in window order
-        RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x1), c.at<float>(ba.mean2), c.at<float>(ba.rstd2), params + bw.n2w,
-                              c.at<float>(w.gx2), c.at<bf16_t>(w.gxbw), grads + bw.n2w, grads + bw.n2b, T, C, CP, &geom, 0, 0, 1, 1,
-                              ds_attn, HW, st));
+        wq[1] = lin_wgrad(c, c.at<bf16_t>(w.du), HP, c.at<bf16_t>(ba.xn2), CP, T, bw.Wfc1, bw.bfc1, fl_mlp);
+        if (!fuse_ln) {
+          // LN2 backward, iterated in window order; emits the (DropPath-scaled) bf16 gradient of x1 in window order
+          RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x1), c.at<float>(ba.mean2), c.at<float>(ba.rstd2),
+                                params + bw.n2w, c.at<float>(w.gx2), c.at<bf16_t>(w.gxbw), grads + bw.n2w, grads + bw.n2b, T, C, CP,
+                                &geom, 0, 0, 1, 1, ds_attn, HW, st));
+        }
         {  // d attn_out = d x1(window order) . Wproj
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gxbw); g.lda = CP; g.Wt = c.packed + bw.WprojT; g.M = T; g.N = bw.CA; g.K = CP;
           g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA; g.flops = fl_proj;
           RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj, fl_proj));
+        wq[2] = lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj, fl_proj);
         RUN(srk_launch_attn_bwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(w.dao), c.at<bf16_t>(w.dqkv),
                                 c.at<float>(w.slab), grads + bw.rpb, T / 64, bw.nH, geom, bw.scale, st));
+        wq[3] = lin_wgrad(c, c.at<bf16_t>(w.dqkv), 3 * bw.CA, c.at<bf16_t>(ba.xn1w), CP, T, bw.Wqkv, bw.bqkv, fl_qkv);
+        RUN(srk_launch_wgrad_multi(wq, 4, st));   // reads gxb2 (as d x2): must precede the kernel that overwrites it
         {  // d xn1 (window order) = d qkv . Wqkv
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.dqkv); g.lda = 3 * bw.CA; g.Wt = c.packed + bw.WqkvT; g.M = T; g.N = CP; g.K = 3 * bw.CA;
-          g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP; g.flops = fl_qkv;
-          RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
+          g.ldo = CP; g.flops = fl_qkv;
+          if (fuse_ln) {   // ... with LN1 backward (+ window reverse + un-roll) fused: gx2[tok] += dx, gxb2 = bf16(gx2 * f_mlp(prev))
+            g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxb2); g.geom = geom; g.rowscale = ds_prev_mlp; g.rows_per_sample = HW;
+            g.ln_x = c.at<float>(ba.x_in); g.ln_mean = c.at<float>(ba.mean1); g.ln_rstd = c.at<float>(ba.rstd1);
+            g.ln_gamma = params + bw.n1w; g.ln_dgamma = grads + bw.n1w; g.ln_dbeta = grads + bw.n1b; g.ln_C = C;
+            g.ln_rows_window = 1; g.ln_stats_by_m = 1; g.ln_out_window = 0;
+            RUN(srk_launch_gemm(LD_ROWS, EP_LNBWD, g, st));
+          } else {
+            g.outb = c.at<bf16_t>(w.dxn);
+            RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
+            // LN1 backward (+ window reverse + un-roll); emits the bf16 gradient for the previous block's MLP branch
+            RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x_in), c.at<float>(ba.mean1), c.at<float>(ba.rstd1),
+                                  params + bw.n1w, c.at<float>(w.gx2), c.at<bf16_t>(w.gxb2), grads + bw.n1w, grads + bw.n1b, T, C, CP,
+                                  &geom, 1, 1, 0, 1, ds_prev_mlp, HW, st));
+          }
         }
-        RUN(lin_wgrad(c, c.at<bf16_t>(w.dqkv), 3 * bw.CA, c.at<bf16_t>(ba.xn1w), CP, T, bw.Wqkv, bw.bqkv, fl_qkv));
-        // LN1 backward (+ window reverse + un-roll); emits the bf16 gradient for the previous block's MLP branch
-        RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x_in), c.at<float>(ba.mean1), c.at<float>(ba.rstd1),
-                              params + bw.n1w, c.at<float>(w.gx2), c.at<bf16_t>(w.gxb2), grads + bw.n1w, grads + bw.n1b, T, C, CP,
-                              &geom, 1, 1, 0, 1, ds_prev_mlp, HW, st));
       }
       // RSTB skip: d(layer input) = d(body input) + d(layer output)
       RUN(srk_launch_add_f32_bf16(c.at<float>(w.gx), c.at<float>(w.gx2), c.at<bf16_t>(w.gxb), (long long)T * CP, st));

@@ -18,4 +18,12 @@ struct WgradParams {
   int r, Cs;         // conv: Y stored pixel-shuffled with factor r, Cs stored channels (r <= 1: plain)
 };
 
+struct WgradMulti {
+  int nprob;
+  int m_per;            // rows per workgroup (set by the launcher)
+  int tile_begin[5];    // prefix sum of tiles per problem
+  WgradParams p[4];
+};
+
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);
+int srk_launch_wgrad_multi(const WgradParams* ps, int nprob, hipStream_t stream);

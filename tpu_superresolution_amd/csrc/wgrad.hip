@@ -15,7 +15,11 @@
 namespace {
 
 template <int TA, int TB, bool CONV>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
+  // several independent problems (same M) share one launch: blockIdx.x -> (problem, tile)
+  int pi = 0;
+  while (pi + 1 < mp.nprob && (int)blockIdx.x >= mp.tile_begin[pi + 1]) ++pi;
+  const WgradParams& p = mp.p[pi];
   constexpr int TN = 64 * TA, TK = 64 * TB;
   constexpr int SY = TN + 8, SX = TK + 8;          // LDS row strides (elements)
   constexpr int PY = (64 * TN / 8) / 256;          // 16-B pieces per thread
@@ -28,14 +32,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int r16 = lane & 15, g = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
   const int ntn = p.N / TN, ntk = p.K / TK;
-  int bx = blockIdx.x;
+  int bx = blockIdx.x - mp.tile_begin[pi];
   const int tn = bx % ntn; bx /= ntn;
   const int tk = bx % ntk; bx /= ntk;
   const int tap = bx;                               // 0 unless CONV
   const int n0 = tn * TN, k0 = tk * TK;
   const int dy = CONV ? tap / 3 - 1 : 0, dx = CONV ? tap % 3 - 1 : 0;
-  const int m_begin = blockIdx.y * p.m_per;
-  const int m_end = min(p.M, m_begin + p.m_per);
+  const int m_begin = blockIdx.y * mp.m_per;
+  const int m_end = min(p.M, m_begin + mp.m_per);
   const int nchunk = (m_end - m_begin + 63) / 64;
   if (nchunk <= 0) return;
 
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 template <int TA, int TB, bool CONV>
-int launch(const WgradParams& p, hipStream_t stream) {
+int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 64 * ((64 * TA + 8) + (64 * TB + 8)) * sizeof(bf16_t);
   static bool configured = false;
   if (!configured) {
@@ -179,42 +183,85 @@ int launch(const WgradParams& p, hipStream_t stream) {
     }
     configured = true;
   }
-  const int tiles = (p.N / (64 * TA)) * (p.K / (64 * TB)) * (CONV ? 9 : 1);
-  WgradParams q = p;
-  // aim at ~2 workgroups per CU worth of work items, at least 256 rows each
-  int splits = cdiv(512, tiles);
-  int m_per = round_up(cdiv(p.M, splits), 64);
+  WgradMulti mp;
+  mp.nprob = nprob;
+  int tiles = 0;
+  double flops = 0.0;
+  for (int i = 0; i < nprob; ++i) {
+    mp.p[i] = ps[i];
+    mp.tile_begin[i] = tiles;
+    tiles += (ps[i].N / (64 * TA)) * (ps[i].K / (64 * TB)) * (CONV ? 9 : 1);
+    flops += ps[i].flops;
+  }
+  mp.tile_begin[nprob] = tiles;
+  // one workgroup per CU (LDS-limited): aim at ~256 workgroups; every split costs one pass of fp32 atomics over dW
+  const int M = ps[0].M;
+  int splits = 256 / tiles;
+  if (splits < 1) splits = 1;
+  int m_per = round_up(cdiv(M, splits), 64);
   if (m_per < 256) m_per = 256;
-  q.m_per = m_per;
-  splits = cdiv(p.M, m_per);
+  mp.m_per = m_per;
+  splits = cdiv(M, m_per);
   const int fam = CONV ? FAM_WGRAD_CONV : FAM_WGRAD_LINEAR;
-  srk_probe_pre(fam, stream, p.flops);
-  hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles, splits), dim3(256), lds, stream, q);
+  srk_probe_pre(fam, stream, flops);
+  hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles, splits), dim3(256), lds, stream, mp);
   srk_probe_post(fam, stream);
   return srk_check_launch("wgrad");
 }
 
+inline void tile_class(const WgradParams& p, int& a, int& b) {
+  a = p.N % 192 == 0 ? 3 : (p.N % 128 == 0 ? 2 : 1);
+  b = p.K % 192 == 0 ? 3 : (p.K % 128 == 0 ? 2 : 1);
+}
+
 template <bool CONV>
-int dispatch(const WgradParams& p, hipStream_t stream) {
-  const int a = p.N % 192 == 0 ? 3 : (p.N % 128 == 0 ? 2 : 1);
-  const int b = p.K % 192 == 0 ? 3 : (p.K % 128 == 0 ? 2 : 1);
+int dispatch(const WgradParams* ps, int nprob, hipStream_t stream) {
+  int a, b;
+  tile_class(ps[0], a, b);
 #define WCASE(A, B) \
-  if (a == A && b == B) return launch<A, B, CONV>(p, stream);
+  if (a == A && b == B) return launch<A, B, CONV>(ps, nprob, stream);
   WCASE(3, 3) WCASE(3, 1) WCASE(1, 3) WCASE(2, 2) WCASE(2, 1) WCASE(1, 2) WCASE(1, 1) WCASE(3, 2) WCASE(2, 3)
 #undef WCASE
-  srk_set_error("wgrad: no tile for N=%d K=%d", p.N, p.K);
+  srk_set_error("wgrad: no tile for N=%d K=%d", ps[0].N, ps[0].K);
   return SRK_E_UNSUPPORTED;
 }
 
-}  // namespace
-
-int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
+int validate(const WgradParams& p) {
   SRK_REQUIRE(p.M > 0 && p.N % 64 == 0 && p.K % 64 == 0, SRK_E_SHAPE, "wgrad: bad M/N/K %d/%d/%d", p.M, p.N, p.K);
   SRK_REQUIRE(p.Y && p.X && p.dW, SRK_E_NULL, "wgrad: null operand");
   if (p.conv) {
     SRK_REQUIRE(p.M == p.B * p.H * p.W, SRK_E_SHAPE, "wgrad(conv): M != B*H*W");
     if (p.r > 1) SRK_REQUIRE(p.Cs % 8 == 0 && p.N == p.r * p.r * p.Cs, SRK_E_SHAPE, "wgrad(conv,ps): bad Cs");
-    return dispatch<true>(p, stream);
   }
-  return dispatch<false>(p, stream);
+  return SRK_OK;
+}
+
+}  // namespace
+
+int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
+  int rc = validate(p);
+  if (rc) return rc;
+  return p.conv ? dispatch<true>(&p, 1, stream) : dispatch<false>(&p, 1, stream);
+}
+
+// Up to 4 linear problems with the same M.  Problems of the same tile class go out as one launch (so that the
+// launch fills the chip with few m-splits, i.e. few atomic passes); the rest are launched one by one.
+int srk_launch_wgrad_multi(const WgradParams* ps, int nprob, hipStream_t stream) {
+  SRK_REQUIRE(nprob >= 1 && nprob <= 4, SRK_E_SHAPE, "wgrad_multi: nprob=%d", nprob);
+  bool same = true;
+  int a0, b0;
+  tile_class(ps[0], a0, b0);
+  for (int i = 0; i < nprob; ++i) {
+    int rc = validate(ps[i]);
+    if (rc) return rc;
+    int a, b;
+    tile_class(ps[i], a, b);
+    same = same && a == a0 && b == b0 && ps[i].M == ps[0].M && !ps[i].conv;
+  }
+  if (same) return dispatch<false>(ps, nprob, stream);
+  for (int i = 0; i < nprob; ++i) {
+    int rc = srk_launch_wgrad(ps[i], stream);
+    if (rc) return rc;
+  }
+  return SRK_OK;
 }
