@@ -134,7 +134,7 @@ int srk_window_attention_fwd(const uint16_t* qkv, const float* bias_dense, uint1
 }
 
 size_t srk_window_attention_bwd_scratch(int64_t B_, int nH) {
-  return (size_t)srk_attn_bwd_slabs(B_, nullptr) * nH * 4096 * sizeof(float);
+  return (size_t)srk_attn_bwd_slabs(B_, nH, nullptr) * nH * 4096 * sizeof(float);
 }
 
 int srk_window_attention_bwd(const uint16_t* qkv, const float* bias_dense, const uint16_t* d_out, uint16_t* d_qkv,

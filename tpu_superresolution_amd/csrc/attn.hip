@@ -208,193 +208,152 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
+// One 4-wave workgroup owns one (window, head) at a time (walking `wpw` windows of the head):
+//   phase 1  wave w = query tile it: S^T[:, it], dP^T[:, it] (8 MFMAs), softmax, dS; P and dS go to LDS as [i][j]
+//   phase 2  wave w = key tile jt:   dV^T[:, jt], dK^T[:, jt] (sum over all 64 queries) and dQ^T[:, it = w]
+// 160 VGPRs per wave and 38 KB of LDS per workgroup -> 3 workgroups (12 waves) per CU hide each other's
+// latencies; the next window's q/k/v/dO tiles are prefetched into registers during phase 2.
+__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
                                                        const bf16_t* __restrict__ dao, bf16_t* __restrict__ dqkv,
                                                        float* __restrict__ dbias_slab, long long B_, int nH, int CA,
                                                        WinGeom geom, int wpw, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int PER_WAVE = 4 * 64 * TS + 64 * PS;  // elements
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * TS], Ks[64 * TS], Vs[64 * TS], Os[64 * TS], Pb[64 * PS], Db[64 * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y;
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw) + wave * PER_WAVE;
-  bf16_t* Ks = Qs + 64 * TS;
-  bf16_t* Vs = Ks + 64 * TS;
-  bf16_t* Os = Vs + 64 * TS;   // dO
-  bf16_t* Pb = Os + 64 * TS;   // P, then dS, as [i][j]
-  const long long slab_id = (long long)blockIdx.x * 4 + wave;
-  const long long w_begin = slab_id * wpw;
+  const long long w_begin = (long long)blockIdx.x * wpw;
   const int ldq = 3 * CA;
+  const int srow = tid >> 2, sch = tid & 3;          // tile staging: 64 rows x 4 chunks of 16 B
+  const float* bias_h = biasd + h * 4096;
 
-  const BiasMem bias = {biasd + h * 4096};
-  f32x4_t dbias[4][4];
+  f32x4_t dbias[4];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) dbias[jt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int jt = 0; jt < 4; ++jt) dbias[jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 preq = make_uint4(0, 0, 0, 0), prek = preq, prev = preq, preo = preq;
+#define ATTN_BWD_PREFETCH(BW)                                                                                     \
+  do {                                                                                                            \
+    preq = *reinterpret_cast<const uint4*>(qkv + ((0 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);        \
+    prek = *reinterpret_cast<const uint4*>(qkv + ((1 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);        \
+    prev = *reinterpret_cast<const uint4*>(qkv + ((2 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);        \
+    preo = *reinterpret_cast<const uint4*>(dao + ((BW) * 64 + srow) * CA + h * 32 + sch * 8);                     \
+  } while (0)
+  if (w_begin < B_) ATTN_BWD_PREFETCH(w_begin);
 
   for (int wi = 0; wi < wpw; ++wi) {
     const long long b_ = w_begin + wi;
     if (b_ >= B_) break;
-    stage_tile_64x32(Qs, qkv + ((0 * B_ + b_) * nH + h) * 2048, 32, lane);
-    stage_tile_64x32(Ks, qkv + ((1 * B_ + b_) * nH + h) * 2048, 32, lane);
-    stage_tile_64x32(Vs, qkv + ((2 * B_ + b_) * nH + h) * 2048, 32, lane);
-    stage_tile_64x32(Os, dao + (b_ * 64) * CA + h * 32, CA, lane);
-    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<uint4*>(Qs + srow * TS + sch * 8) = preq;
+    *reinterpret_cast<uint4*>(Ks + srow * TS + sch * 8) = prek;
+    *reinterpret_cast<uint4*>(Vs + srow * TS + sch * 8) = prev;
+    *reinterpret_cast<uint4*>(Os + srow * TS + sch * 8) = preo;
+    __syncthreads();
+    if (wi + 1 < wpw && b_ + 1 < B_) ATTN_BWD_PREFETCH(b_ + 1);
 
-    // S^T and dP^T (both [j][i], sum over d)
-    f32x4_t s[4][4], dp[4][4];
+    // ---- phase 1: this wave's 16 queries (it = wave) against all 64 keys -----------------------
+    const int it = wave;
+    f32x4_t s[4], dp[4];
     {
-      bf16x8_t kf[4], qf[4], vf[4], of[4];
+      const bf16x8_t qf = row_frag(Qs, TS, 16 * it + r16, 8 * g);
+      const bf16x8_t of = row_frag(Os, TS, 16 * it + r16, 8 * g);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        kf[t] = row_frag(Ks, TS, 16 * t + r16, 8 * g);
-        qf[t] = row_frag(Qs, TS, 16 * t + r16, 8 * g);
-        vf[t] = row_frag(Vs, TS, 16 * t + r16, 8 * g);
-        of[t] = row_frag(Os, TS, 16 * t + r16, 8 * g);
+      for (int jt = 0; jt < 4; ++jt) {
+        const bf16x8_t kf = row_frag(Ks, TS, 16 * jt + r16, 8 * g);
+        const bf16x8_t vf = row_frag(Vs, TS, 16 * jt + r16, 8 * g);
+        s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
+    }
+    {  // + bias + mask, softmax over the 64 keys of column i = 16 it + r16
+      const int w = (int)b_ % geom.nW;
+      const int wy = w / geom.nWw, wx = w - wy * geom.nWw;
+      const bool masked = geom.shift > 0 && (wy == geom.H / 8 - 1 || wx == geom.nWw - 1);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_h + (16 * it + r16) * 64 + 16 * jt + 4 * g);
+        s[jt] += f32x4_t{bv.x, bv.y, bv.z, bv.w};
+      }
+      if (masked) {
+        const int labi = win_region_label(geom, w, 16 * it + r16);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (win_region_label(geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;
+      }
+      float mx = -3.0e38f;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          s[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          dp[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt], of[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-    }
-    softmax_T(s, bias, geom, (int)(b_ % geom.nW), lane);
-
-    // P -> LDS as [i][j] (bf16), then dS = P o (dP - rowsum(P o dP))
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      float dl = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        *reinterpret_cast<uint2*>(Pb + (16 * it + r16) * PS + 16 * jt + 4 * g) =
-            pack_bf4(s[jt][it][0], s[jt][it][1], s[jt][it][2], s[jt][it][3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dl += s[jt][it][e] * dp[jt][it][e];
-      }
-      dl = xsum4(dl);
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
+      mx = xmax4(mx);
+      float sum = 0.f;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float ds = s[jt][it][e] * (dp[jt][it][e] - dl);
-          dp[jt][it][e] = ds;
-          dbias[jt][it][e] += ds;
+          s[jt][e] = __expf(s[jt][e] - mx);
+          sum += s[jt][e];
         }
+      const float inv = 1.0f / xsum4(sum);
+      float dl = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[jt][e] *= inv;
+          dl += s[jt][e] * dp[jt][e];
+        }
+      dl = xsum4(dl);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dp[jt][e] = s[jt][e] * (dp[jt][e] - dl);       // dS
+          dbias[jt][e] += dp[jt][e];
+        }
+        *reinterpret_cast<uint2*>(Pb + (16 * it + r16) * PS + 16 * jt + 4 * g) = pack_bf4(s[jt][0], s[jt][1], s[jt][2], s[jt][3]);
+        *reinterpret_cast<uint2*>(Db + (16 * it + r16) * PS + 16 * jt + 4 * g) = pack_bf4(dp[jt][0], dp[jt][1], dp[jt][2], dp[jt][3]);
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
-    // dV^T[d][j] = sum_i dO^T[d][i] P[i][j]
+    // ---- phase 2: this wave's 16 keys (jt = wave) for dV / dK, its 16 queries for dQ --------------
     {
-      f32x4_t acc[2][4];
+      f32x4_t av[2], ak[2], aq[2];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[dt][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int dt = 0; dt < 2; ++dt) av[dt] = ak[dt] = aq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        bf16x8_t af[2], bfr[4];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) af[dt] = tr_frag_nat(Os, TS, 32 * ss, 16 * dt, lane);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) bfr[jt] = tr_frag_nat(Pb, PS, 32 * ss, 16 * jt, lane);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-            acc[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[jt], acc[dt][jt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+        const bf16x8_t pf = tr_frag_nat(Pb, PS, 32 * ss, 16 * wave, lane);     // P[i][j in tile]  (k = i)
+        const bf16x8_t df = tr_frag_nat(Db, PS, 32 * ss, 16 * wave, lane);     // dS[i][j in tile] (k = i)
+        const bf16x8_t dr = row_frag(Db, PS, 16 * wave + r16, 32 * ss + 8 * g); // dS[i in tile][j] (k = j)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          bf16_t* dst = dqkv + (b_ * 64 + 16 * jt + r16) * ldq + 2 * CA + h * 32 + 16 * dt + 4 * g;
-          *reinterpret_cast<uint2*>(dst) = pack_bf4(acc[dt][jt][0], acc[dt][jt][1], acc[dt][jt][2], acc[dt][jt][3]);
+          av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_nat(Os, TS, 32 * ss, 16 * dt, lane), pf, av[dt], 0, 0, 0);
+          ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_nat(Qs, TS, 32 * ss, 16 * dt, lane), df, ak[dt], 0, 0, 0);
+          aq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_nat(Ks, TS, 32 * ss, 16 * dt, lane), dr, aq[dt], 0, 0, 0);
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // dS -> LDS as [i][j]
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-        *reinterpret_cast<uint2*>(Pb + (16 * it + r16) * PS + 16 * jt + 4 * g) =
-            pack_bf4(dp[jt][it][0], dp[jt][it][1], dp[jt][it][2], dp[jt][it][3]);
-    __builtin_amdgcn_wave_barrier();
-
-    // dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]        (Q is already scaled)
-    {
-      f32x4_t acc[2][4];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[dt][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        bf16x8_t af[2], bfr[4];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) af[dt] = tr_frag_nat(Qs, TS, 32 * ss, 16 * dt, lane);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) bfr[jt] = tr_frag_nat(Pb, PS, 32 * ss, 16 * jt, lane);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-            acc[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[jt], acc[dt][jt], 0, 0, 0);
       }
+      bf16_t* row = dqkv + (b_ * 64 + 16 * wave + r16) * ldq + h * 32 + 4 * g;
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          bf16_t* dst = dqkv + (b_ * 64 + 16 * jt + r16) * ldq + 1 * CA + h * 32 + 16 * dt + 4 * g;
-          *reinterpret_cast<uint2*>(dst) = pack_bf4(acc[dt][jt][0], acc[dt][jt][1], acc[dt][jt][2], acc[dt][jt][3]);
-        }
-    }
-    // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i]
-    {
-      f32x4_t acc[2][4];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        bf16x8_t af[2], bfr[4];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) af[dt] = tr_frag_nat(Ks, TS, 32 * ss, 16 * dt, lane);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) bfr[it] = row_frag(Pb, PS, 16 * it + r16, 32 * ss + 8 * g);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int it = 0; it < 4; ++it)
-            acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[it], acc[dt][it], 0, 0, 0);
+      for (int dt = 0; dt < 2; ++dt) {
+        *reinterpret_cast<uint2*>(row + 16 * dt) = pack_bf4(aq[dt][0] * scale, aq[dt][1] * scale, aq[dt][2] * scale, aq[dt][3] * scale);
+        *reinterpret_cast<uint2*>(row + CA + 16 * dt) = pack_bf4(ak[dt][0], ak[dt][1], ak[dt][2], ak[dt][3]);
+        *reinterpret_cast<uint2*>(row + 2 * CA + 16 * dt) = pack_bf4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
       }
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          bf16_t* dst = dqkv + (b_ * 64 + 16 * it + r16) * ldq + 0 * CA + h * 32 + 16 * dt + 4 * g;
-          *reinterpret_cast<uint2*>(dst) =
-              pack_bf4(acc[dt][it][0] * scale, acc[dt][it][1] * scale, acc[dt][it][2] * scale, acc[dt][it][3] * scale);
-        }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 
-  // per-wave partial d(bias) slab, dense [i][j]
-  float* slab = dbias_slab + ((slab_id * nH + h) * 64) * 64;
+  // per-workgroup partial d(bias) slab, dense [i][j]; this wave owns the rows i = 16 wave + r16
+  float* slab = dbias_slab + (((long long)blockIdx.x * nH + h) * 64) * 64;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-      *reinterpret_cast<float4*>(slab + (16 * it + r16) * 64 + 16 * jt + 4 * g) =
-          make_float4(dbias[jt][it][0], dbias[jt][it][1], dbias[jt][it][2], dbias[jt][it][3]);
+    *reinterpret_cast<float4*>(slab + (16 * wave + r16) * 64 + 16 * jt + 4 * g) =
+        make_float4(dbias[jt][0], dbias[jt][1], dbias[jt][2], dbias[jt][3]);
 }
 
-// d(table)[t][h] += sum over slabs and over (i,j) with rpi(i,j) == t.  One workgroup per (t, h).
 // One workgroup per (query token i, head h): the 4 waves sum row i of every slab (256-B coalesced reads, lane = key
 // token j), combine through LDS, and scatter the 64 row sums into the table with rpi(i, j).
 __global__ __launch_bounds__(256) void rpb_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dtable,
@@ -434,31 +393,24 @@ int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long 
   return srk_check_launch("attn_fwd");
 }
 
-int srk_attn_bwd_slabs(long long B_, int* wpw_out) {
-  const int wpw = B_ >= 1024 ? 8 : 1;
-  if (wpw_out) *wpw_out = wpw;
-  const long long blocks = (B_ + 4 * wpw - 1) / (4 * wpw);
-  return (int)(blocks * 4);
+int srk_attn_bwd_slabs(long long B_, int nH, int* wpw_out) {
+  // windows per workgroup: as few as possible while all workgroups are resident at once (3 per CU: 160 VGPRs)
+  const long long slots = 3 * 256;
+  long long wpw = (B_ * nH + slots - 1) / slots;
+  if (wpw < 1) wpw = 1;
+  while (((B_ + wpw - 1) / wpw) * nH > slots && wpw < B_) ++wpw;
+  if (wpw_out) *wpw_out = (int)wpw;
+  return (int)((B_ + wpw - 1) / wpw);
 }
 
 int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,
                         float* dtable, long long B_, int nH, WinGeom geom, float scale, hipStream_t stream) {
   int wpw;
-  const int nslab = srk_attn_bwd_slabs(B_, &wpw);
-  constexpr size_t lds = (size_t)4 * (4 * 64 * TS + 64 * PS) * sizeof(bf16_t);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      srk_set_error("attn_bwd: cannot reserve %zu bytes of LDS", lds);
-      return SRK_E_LAUNCH;
-    }
-    configured = true;
-  }
-  dim3 grid(nslab / 4, nH);
+  const int nslab = srk_attn_bwd_slabs(B_, nH, &wpw);
+  dim3 grid(nslab, nH);
   srk_probe_pre(FAM_ATTN_BWD, stream, 0.0);
-  hipLaunchKernelGGL(attn_bwd_kernel, grid, dim3(256), lds, stream, qkv, biasd, dao, dqkv, dbias_slab, B_, nH, nH * 32,
-                     geom, wpw, scale);
+  hipLaunchKernelGGL(attn_bwd_kernel, grid, dim3(256), 0, stream, qkv, biasd, dao, dqkv, dbias_slab, B_, nH, nH * 32, geom,
+                     wpw, scale);
   srk_probe_post(FAM_ATTN_BWD, stream);
   int rc = srk_check_launch("attn_bwd");
   if (rc) return rc;

@@ -67,6 +67,16 @@ struct GemmParams {
   float* ln_dbeta;
   int ln_C;               // real channel count
   int ln_rows_window, ln_stats_by_m, ln_out_window;
+  // EP_PROJ_RES / EP_RES: optional fused forward LayerNorm of the freshly written residual row (the norm that
+  // consumes it next: norm2 after proj, the next block's norm1 / the final norm after fc2 / the RSTB conv).
+  // Needs N == one tile.  xn_out row = xn_window ? winrow(xn_geom, token) : token; stats are stored at that row.
+  bf16_t* xn_out;
+  float* xn_mean;
+  float* xn_rstd;
+  const float* xn_gamma;
+  const float* xn_beta;
+  int xn_C, xn_window;
+  WinGeom xn_geom;
 };
 
 int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t stream);

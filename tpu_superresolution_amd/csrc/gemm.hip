@@ -309,6 +309,11 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
   } else {
     SRK_REQUIRE(p.lda >= p.K && p.lda % 8 == 0, SRK_E_SHAPE, "gemm: bad lda %d", p.lda);
   }
+  if (p.xn_out) {
+    SRK_REQUIRE((epilogue == EP_PROJ_RES || epilogue == EP_RES) && (p.N == 64 || p.N == 128 || p.N == 192), SRK_E_SHAPE,
+                "gemm: fused LayerNorm output needs a residual epilogue and N in {64,128,192} (N=%d)", p.N);
+    SRK_REQUIRE(p.xn_mean && p.xn_rstd && p.xn_gamma && p.xn_beta, SRK_E_NULL, "gemm: fused LayerNorm: null pointer");
+  }
 #define CASE(LD, EP) \
   if (loader == LD && epilogue == EP) return dispatch_nt<LD, EP>(p, stream);
   CASE(LD_ROWS, EP_BF16)

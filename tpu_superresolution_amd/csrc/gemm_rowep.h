@@ -10,6 +10,43 @@
 #pragma once
 #include "gemm.h"
 
+// LayerNorm (eps 1e-5) of a row held as NC float4 per lane by a 16-lane group -> bf16 row + stats
+template <int NC>
+__device__ __forceinline__ void fused_ln_row(const GemmParams& p, const float4 (&o)[NC], long long t, int j16,
+                                             const float (&lg)[NC][4], const float (&lb)[NC][4]) {
+  const float invC = 1.0f / (float)p.xn_C;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s += (o[c].x + o[c].y) + (o[c].z + o[c].w);     // pad columns are zero
+  const float mean = wave_sum16(s) * invC;
+  float d[NC][4];
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float ov[4] = {o[c].x, o[c].y, o[c].z, o[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d[c][e] = 64 * c + 4 * j16 + e < p.xn_C ? ov[e] - mean : 0.f;
+      q += d[c][e] * d[c][e];
+    }
+  }
+  const float rstd = rsqrtf(wave_sum16(q) * invC + 1e-5f);
+  const long long ro = p.xn_window ? token_to_win_row(p.xn_geom, (int)t) : t;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y[e] = d[c][e] * rstd * lg[c][e] + lb[c][e];     // gamma/beta are zero in the pad columns
+    }
+    *reinterpret_cast<uint2*>(p.xn_out + ro * p.ldo + 64 * c + 4 * j16) = pack_bf4(y[0], y[1], y[2], y[3]);
+  }
+  if (j16 == 0) {
+    p.xn_mean[ro] = mean;
+    p.xn_rstd[ro] = rstd;
+  }
+}
+
 template <int EP, int NTT>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t (&acc)[4][NTT], unsigned char* smem, int m0,
                                                    int n0, int tid) {
@@ -43,6 +80,20 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
       }
   }
   const float invC = EP == EP_LNBWD ? 1.0f / (float)p.ln_C : 0.f;
+  // fused forward LayerNorm (EP_PROJ_RES / EP_RES): per-lane gamma / beta of this lane's columns
+  float lg[NC][4], lb[NC][4];
+  if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
+    if (p.xn_out) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 64 * c + 4 * j16 + e;
+          lg[c][e] = n < p.xn_C ? p.xn_gamma[n] : 0.f;
+          lb[c][e] = n < p.xn_C ? p.xn_beta[n] : 0.f;
+        }
+    }
+  }
 
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -103,14 +154,17 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
       } else if constexpr (EP == EP_PROJ_RES) {
         const long long t = win_row_to_token(p.geom, m);
         const float f = p.rowscale ? p.rowscale[t / p.rows_per_sample] : 1.0f;
+        float4 o[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int n = n0 + 64 * c + 4 * j16;
+          o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (n >= p.N) continue;
           const float4 rv = *reinterpret_cast<const float4*>(p.res + t * p.ldo + n);
-          *reinterpret_cast<float4*>(p.outf + t * p.ldo + n) =
-              make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
+          o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
+          *reinterpret_cast<float4*>(p.outf + t * p.ldo + n) = o[c];
         }
+        if (p.xn_out) fused_ln_row<NC>(p, o, t, j16, lg, lb);
       } else if constexpr (EP == EP_GELU) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -122,15 +176,20 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
         }
       } else if constexpr (EP == EP_RES || EP == EP_RES_BF16) {
         const float f = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+        float4 o[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int n = n0 + 64 * c + 4 * j16;
+          o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (n >= p.N) continue;
           const float4 rv = *reinterpret_cast<const float4*>(p.res + (long long)m * p.ldo + n);
-          const float4 o = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
-          if constexpr (EP == EP_RES) *reinterpret_cast<float4*>(p.outf + (long long)m * p.ldo + n) = o;
+          o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
+          if constexpr (EP == EP_RES) *reinterpret_cast<float4*>(p.outf + (long long)m * p.ldo + n) = o[c];
           if (EP == EP_RES_BF16 || p.outb)
-            *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(o.x, o.y, o.z, o.w);
+            *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w);
+        }
+        if constexpr (EP == EP_RES) {
+          if (p.xn_out) fused_ln_row<NC>(p, o, m, j16, lg, lb);
         }
       } else if constexpr (EP == EP_DGELU || EP == EP_DLRELU) {
 #pragma unroll

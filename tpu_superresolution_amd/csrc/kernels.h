@@ -6,7 +6,7 @@
 #include "wgrad.h"
 
 int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long long B_, int nH, WinGeom geom, hipStream_t stream);
-int srk_attn_bwd_slabs(long long B_, int* wpw_out);
+int srk_attn_bwd_slabs(long long B_, int nH, int* wpw_out);
 int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,
                         float* dtable, long long B_, int nH, WinGeom geom, float scale, hipStream_t stream);
 int srk_launch_rpb_expand(const float* table, float* biasd, int nH, hipStream_t stream);

@@ -288,7 +288,7 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
     w.dqkv = a.get("dqkv", T * 3 * maxCA * 2);
     int maxH = 1;
     for (const BlockW& b : p->blocks) maxH = b.nH > maxH ? b.nH : maxH;
-    w.slab = a.get("slab", (size_t)srk_attn_bwd_slabs(w.T / 64, nullptr) * maxH * 4096 * 4);
+    w.slab = a.get("slab", (size_t)srk_attn_bwd_slabs(w.T / 64, 1, nullptr) * maxH * 4096 * 4);
     w.gfb = a.get("gfb", T * CP * 2);
     w.gfb32 = a.get("gfb32", T * CP * 4);
     if (p->cfg.upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
@@ -571,6 +571,8 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
   const int HW = H * W;
   hipStream_t st = c.stream;
   const double fl_qkv = 2.0 * T * 3 * C * C, fl_proj = 2.0 * T * C * C, fl_mlp = 2.0 * T * (double)p->HID * C;
+  const bool fuse_ln = CP == 64 || CP == 128 || CP == 192;   // forward LayerNorms ride in the producing GEMM's epilogue
+  bool ln1_done = false;
 
   RUN(srk_launch_img_prep(x, c.at<float>(w.img4), B, p->Cimg, H0, W0, H, W, p->cfg.img_range, p->cfg.mean, st));
   RUN(srk_launch_stem_conv(c.at<float>(w.img4), params + p->p_conv_first_w, params + p->p_conv_first_b, c.at<float>(w.f0), B, H,
@@ -588,8 +590,11 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
       const float* ds_attn = drop_scale ? drop_scale + ((size_t)bi * 2 + 0) * B : nullptr;
       const float* ds_mlp = drop_scale ? drop_scale + ((size_t)bi * 2 + 1) * B : nullptr;
       // LN1 (+ roll + window partition)            network_swinir.py:245-256
-      RUN(srk_launch_ln_fwd(c.at<float>(ba.x_in), params + bw.n1w, params + bw.n1b, c.at<bf16_t>(ba.xn1w), nullptr,
-                            c.at<float>(ba.mean1), c.at<float>(ba.rstd1), T, C, CP, &geom, st));
+      // (normally already produced by the epilogue of the kernel that wrote x_in: fc2 of the previous block / RSTB conv)
+      if (!ln1_done)
+        RUN(srk_launch_ln_fwd(c.at<float>(ba.x_in), params + bw.n1w, params + bw.n1b, c.at<bf16_t>(ba.xn1w), nullptr,
+                              c.at<float>(ba.mean1), c.at<float>(ba.rstd1), T, C, CP, &geom, st));
+      ln1_done = false;
       {  // qkv projection, q scaled                  :121-124
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.xn1w); g.lda = CP; g.Wt = c.packed + bw.Wqkv; g.M = T; g.N = 3 * bw.CA; g.K = CP;
@@ -604,11 +609,15 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         g.A = c.at<bf16_t>(ba.ao); g.lda = bw.CA; g.Wt = c.packed + bw.Wproj; g.M = T; g.N = CP; g.K = bw.CA;
         g.bias = c.side + bw.bproj; g.res = c.at<float>(ba.x_in); g.outf = c.at<float>(ba.x1); g.ldo = CP; g.geom = geom;
         g.rowscale = ds_attn; g.rows_per_sample = HW; g.flops = fl_proj;
+        if (fuse_ln) {   // LN2 (:277) of the row just written, fused into the epilogue
+          g.xn_out = c.at<bf16_t>(ba.xn2); g.xn_mean = c.at<float>(ba.mean2); g.xn_rstd = c.at<float>(ba.rstd2);
+          g.xn_gamma = params + bw.n2w; g.xn_beta = params + bw.n2b; g.xn_C = C; g.xn_window = 0;
+        }
         RUN(srk_launch_gemm(LD_ROWS, EP_PROJ_RES, g, st));
       }
-      // LN2                                          :277
-      RUN(srk_launch_ln_fwd(c.at<float>(ba.x1), params + bw.n2w, params + bw.n2b, c.at<bf16_t>(ba.xn2), nullptr,
-                            c.at<float>(ba.mean2), c.at<float>(ba.rstd2), T, C, CP, nullptr, st));
+      if (!fuse_ln)   // LN2                           :277
+        RUN(srk_launch_ln_fwd(c.at<float>(ba.x1), params + bw.n2w, params + bw.n2b, c.at<bf16_t>(ba.xn2), nullptr,
+                              c.at<float>(ba.mean2), c.at<float>(ba.rstd2), T, C, CP, nullptr, st));
       {  // fc1 + GELU                                 :25-26
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.xn2); g.lda = CP; g.Wt = c.packed + bw.Wfc1; g.M = T; g.N = HP; g.K = CP;
@@ -621,19 +630,39 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         g.bias = c.side + bw.bfc2; g.res = c.at<float>(ba.x1); g.outf = c.at<float>(ba.x_out); g.ldo = CP;
         g.outb = (j == depth - 1) ? c.at<bf16_t>(w.layer_xb[l]) : nullptr;
         g.rowscale = ds_mlp; g.rows_per_sample = HW; g.flops = fl_mlp;
+        if (fuse_ln && j + 1 < depth) {   // next block's norm1 (+ its roll + window partition) fused into this epilogue
+          const BlockW& nb = p->blocks[bi + 1];
+          const BlockAct& na = w.blk[bi + 1];
+          g.xn_out = c.at<bf16_t>(na.xn1w); g.xn_mean = c.at<float>(na.mean1); g.xn_rstd = c.at<float>(na.rstd1);
+          g.xn_gamma = params + nb.n1w; g.xn_beta = params + nb.n1b; g.xn_C = C; g.xn_window = 1;
+          g.xn_geom = make_wgeom(H, W, nb.shift);
+          ln1_done = true;
+        }
         RUN(srk_launch_gemm(LD_ROWS, EP_RES, g, st));
       }
     }
     {  // RSTB conv + residual                          :481-482
       GemmParams g = {};
       g.res = c.at<float>(w.layer_in[l]); g.outf = c.at<float>(w.layer_out[l]); g.ldo = CP;
+      if (fuse_ln && l + 1 < p->L) {     // norm1 of the next RSTB's first block
+        const int nbi = p->layer_first_blk[l + 1];
+        const BlockW& nb = p->blocks[nbi];
+        const BlockAct& na = w.blk[nbi];
+        g.xn_out = c.at<bf16_t>(na.xn1w); g.xn_mean = c.at<float>(na.mean1); g.xn_rstd = c.at<float>(na.rstd1);
+        g.xn_gamma = params + nb.n1w; g.xn_beta = params + nb.n1b; g.xn_C = C; g.xn_window = 1;
+        g.xn_geom = make_wgeom(H, W, nb.shift);
+        ln1_done = true;
+      } else if (fuse_ln) {              // final norm (:800)
+        g.xn_out = c.at<bf16_t>(w.xnf); g.xn_mean = c.at<float>(w.meanf); g.xn_rstd = c.at<float>(w.rstdf);
+        g.xn_gamma = params + p->p_norm_w; g.xn_beta = params + p->p_norm_b; g.xn_C = C; g.xn_window = 0;
+      }
       RUN(run_conv(c, p->layer_conv[l], LD_CONV3, EP_RES, c.at<bf16_t>(w.layer_xb[l]), B, H, W, g));
     }
   }
   const size_t x_final = w.layer_out[p->L - 1];
-  // final norm                                         :800
-  RUN(srk_launch_ln_fwd(c.at<float>(x_final), params + p->p_norm_w, params + p->p_norm_b, c.at<bf16_t>(w.xnf), nullptr,
-                        c.at<float>(w.meanf), c.at<float>(w.rstdf), T, C, CP, nullptr, st));
+  if (!fuse_ln)   // final norm                          :800
+    RUN(srk_launch_ln_fwd(c.at<float>(x_final), params + p->p_norm_w, params + p->p_norm_b, c.at<bf16_t>(w.xnf), nullptr,
+                          c.at<float>(w.meanf), c.at<float>(w.rstdf), T, C, CP, nullptr, st));
   {  // conv_after_body + long skip                      :815
     GemmParams g = {};
     g.res = c.at<float>(w.f0); g.outb = c.at<bf16_t>(w.fb); g.ldo = CP;
