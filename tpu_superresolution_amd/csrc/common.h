@@ -96,6 +96,15 @@ __device__ __forceinline__ int win_row_to_token(const WinGeom& g, int m) {
   return (b * g.H + y) * g.W + x;
 }
 
+// XCD-aware block remap (bijective for any grid size): hardware deals consecutive block ids round-robin over
+// the 8 XCDs (each with a private L2), so blocks b and b+8 share an XCD.  Returning a LOGICAL id that is contiguous
+// per XCD makes consecutive logical tiles (which share operand panels) hit the same L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // inverse of win_row_to_token: raster token -> window-order row
 __device__ __forceinline__ int token_to_win_row(const WinGeom& g, int t) {
   const int hw = g.H * g.W;

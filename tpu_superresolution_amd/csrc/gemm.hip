@@ -37,8 +37,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int r16 = lane & 15, g = lane >> 4;
   const int wm = NARROW ? wave : (wave >> 1);
   const int wn = NARROW ? 0 : (wave & 1);
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // 1-D grid; logical tile order is n-chunk fastest and contiguous per XCD, so the N-chunks of one M-tile (which
+  // re-read the same A rows) run back to back on one XCD and share its L2
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
   const int srow = tid >> 3, schunk = tid & 7;  // staging: 32 rows x 8 chunks per pass
 
   // ---- per-thread A row contexts ------------------------------------------------------------
@@ -279,7 +283,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     }
     configured = true;
   }
-  dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN));
+  dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN));
   const int fam = LD == LD_ROWS ? FAM_GEMM_LINEAR : FAM_GEMM_CONV;
   srk_probe_pre(fam, stream, p.flops);
   hipLaunchKernelGGL((gemm_kernel<LD, EP, NT, NARROW>), grid, dim3(256), lds, stream, p);

@@ -111,8 +111,46 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
         for (int i = tid; i < 2 * BN; i += 256) colred[i] = 0.f;
     }
     __syncthreads();
+    // Global operands of the row epilogue are fetched for a batch of rows BEFORE any of them is consumed: the
+    // compiler cannot hoist these loads above the previous row's stores (possible aliasing), and at 2 workgroups
+    // per CU a dependent load-use-store chain per row would serialise ~8 memory round trips per tile.
+    constexpr int PFB = (EP == EP_LNBWD || EP == EP_PROJ_RES || EP == EP_RES) ? 1 : 4;   // measured: batching only pays for the bf16-aux epilogues
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it0 = 0; it0 < 4; it0 += PFB) {
+      float4 pf_a[PFB][NC], pf_b[PFB][NC];
+      uint2 pf_u[PFB][NC];
+      float pf_mean[PFB], pf_rstd[PFB];
+#pragma unroll
+      for (int u = 0; u < PFB; ++u) {
+        const int lr = wave * 16 + (it0 + u) * 4 + sub;
+        const int m = m0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int n = n0 + 64 * c + 4 * j16;
+          if (n >= p.N) continue;
+          if constexpr (EP == EP_PROJ_RES) {
+            pf_a[u][c] = *reinterpret_cast<const float4*>(p.res + (long long)win_row_to_token(p.geom, m) * p.ldo + n);
+          } else if constexpr (EP == EP_RES || EP == EP_RES_BF16) {
+            pf_a[u][c] = *reinterpret_cast<const float4*>(p.res + (long long)m * p.ldo + n);
+          } else if constexpr (EP == EP_DGELU || EP == EP_DLRELU) {
+            pf_u[u][c] = *reinterpret_cast<const uint2*>(p.aux + (long long)m * p.ldo + n);
+          } else if constexpr (EP == EP_LNBWD) {
+            const long long t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
+            pf_a[u][c] = *reinterpret_cast<const float4*>(p.ln_x + t * p.ldo + n);
+            pf_b[u][c] = *reinterpret_cast<const float4*>(p.outf + t * p.ldo + n);
+          }
+        }
+        if constexpr (EP == EP_LNBWD) {
+          const long long t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
+          const long long st = p.ln_stats_by_m ? m : t;
+          pf_mean[u] = p.ln_mean[st];
+          pf_rstd[u] = p.ln_rstd[st];
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < PFB; ++u) {
+      const int it = it0 + u;
       const int lr = wave * 16 + it * 4 + sub;
       const int m = m0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
       if (m >= p.M) continue;
@@ -160,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           const int n = n0 + 64 * c + 4 * j16;
           o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (n >= p.N) continue;
-          const float4 rv = *reinterpret_cast<const float4*>(p.res + t * p.ldo + n);
+          const float4 rv = pf_a[u][c];
           o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
           *reinterpret_cast<float4*>(p.outf + t * p.ldo + n) = o[c];
         }
@@ -182,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           const int n = n0 + 64 * c + 4 * j16;
           o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (n >= p.N) continue;
-          const float4 rv = *reinterpret_cast<const float4*>(p.res + (long long)m * p.ldo + n);
+          const float4 rv = pf_a[u][c];
           o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
           if constexpr (EP == EP_RES) *reinterpret_cast<float4*>(p.outf + (long long)m * p.ldo + n) = o[c];
           if (EP == EP_RES_BF16 || p.outb)
@@ -196,10 +234,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
         for (int c = 0; c < NC; ++c) {
           const int n = n0 + 64 * c + 4 * j16;
           if (n >= p.N) continue;
-          const uint2 u = *reinterpret_cast<const uint2*>(p.aux + (long long)m * p.ldo + n);
+          const uint2 ua = pf_u[u][c];
           float u0, u1, u2, u3;
-          unpack_bf2(u.x, u0, u1);
-          unpack_bf2(u.y, u2, u3);
+          unpack_bf2(ua.x, u0, u1);
+          unpack_bf2(ua.y, u2, u3);
           uint2 o;
           if constexpr (EP == EP_DGELU) {
             o = pack_bf4(v[c].x * dgelu_f(u0), v[c].y * dgelu_f(u1), v[c].z * dgelu_f(u2), v[c].w * dgelu_f(u3));
@@ -236,13 +274,12 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
       } else if constexpr (EP == EP_LNBWD) {
         // v = dL/d(LN output) of row m (all BN columns live in this 16-lane group)
         const long long t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
-        const long long st = p.ln_stats_by_m ? m : t;
-        const float mean = p.ln_mean[st], rstd = p.ln_rstd[st];
+        const float mean = pf_mean[u], rstd = pf_rstd[u];
         float xh[NC][4], dy[NC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const float4 xv = *reinterpret_cast<const float4*>(p.ln_x + t * p.ldo + 64 * c + 4 * j16);
+          const float4 xv = pf_a[u][c];
           const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
           const float dv[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
@@ -261,7 +298,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           float* gp = p.outf + t * p.ldo + 64 * c + 4 * j16;
-          const float4 old = *reinterpret_cast<const float4*>(gp);
+          const float4 old = pf_b[u][c];
           float o[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -276,6 +313,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
             *reinterpret_cast<uint2*>(p.outb + ro * p.ldo + 64 * c + 4 * j16) = pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f);
         }
       }
+    }
     }
   }
   if constexpr (EP == EP_LNBWD) {

@@ -17,8 +17,13 @@ namespace {
 template <int TA, int TB, bool CONV>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
   // several independent problems (same M) share one launch: blockIdx.x -> (problem, tile)
+  // 1-D grid, logical order = (m-split, tile) with the tiles of one m-split contiguous on one XCD: they re-read the
+  // same X / Y rows, which then come from that XCD's L2
+  const int ntiles = mp.tile_begin[mp.nprob];
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bsplit = logical / ntiles, btile = logical - bsplit * ntiles;
   int pi = 0;
-  while (pi + 1 < mp.nprob && (int)blockIdx.x >= mp.tile_begin[pi + 1]) ++pi;
+  while (pi + 1 < mp.nprob && btile >= mp.tile_begin[pi + 1]) ++pi;
   const WgradParams& p = mp.p[pi];
   constexpr int TN = 64 * TA, TK = 64 * TB;
   constexpr int SY = TN + 8, SX = TK + 8;          // LDS row strides (elements)
@@ -32,13 +37,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
   const int r16 = lane & 15, g = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
   const int ntn = p.N / TN, ntk = p.K / TK;
-  int bx = blockIdx.x - mp.tile_begin[pi];
+  int bx = btile - mp.tile_begin[pi];
   const int tn = bx % ntn; bx /= ntn;
   const int tk = bx % ntk; bx /= ntk;
   const int tap = bx;                               // 0 unless CONV
   const int n0 = tn * TN, k0 = tk * TK;
   const int dy = CONV ? tap / 3 - 1 : 0, dx = CONV ? tap % 3 - 1 : 0;
-  const int m_begin = blockIdx.y * mp.m_per;
+  const int m_begin = bsplit * mp.m_per;
   const int m_end = min(p.M, m_begin + mp.m_per);
   const int nchunk = (m_end - m_begin + 63) / 64;
   if (nchunk <= 0) return;
@@ -204,7 +209,7 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   splits = cdiv(M, m_per);
   const int fam = CONV ? FAM_WGRAD_CONV : FAM_WGRAD_LINEAR;
   srk_probe_pre(fam, stream, flops);
-  hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles, splits), dim3(256), lds, stream, mp);
+  hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles * splits), dim3(256), lds, stream, mp);
   srk_probe_post(fam, stream);
   return srk_check_launch("wgrad");
 }
