@@ -1,0 +1,65 @@
+"""Host-side data path (CPU) and the finetune entry point end-to-end on a synthetic dataset (GPU)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+
+def make_dataset(root, n_train=6, n_valid=2, lr=72, scale=4):
+    rng = np.random.RandomState(0)
+    for split, n in (("train", n_train), ("valid", n_valid)):
+        hr_dir = os.path.join(root, "shuffled2D", f"shuffled2D_{split}_HR")
+        lr_dir = os.path.join(root, "shuffled2D", f"shuffled2D_{split}_LR_default_X{scale}")
+        os.makedirs(hr_dir)
+        os.makedirs(lr_dir)
+        for i in range(n):
+            hr = (rng.rand(lr * scale, lr * scale) * 255).astype(np.uint8)
+            Image.fromarray(hr, "L").save(os.path.join(hr_dir, f"{i:04d}.png"))
+            Image.fromarray(hr, "L").resize((lr, lr), Image.BICUBIC).save(os.path.join(lr_dir, f"{i:04d}x{scale}.png"))
+
+
+def test_dataset_pairs_and_transforms(tmp_path):
+    from tpu_superresolution_amd.sr_datasets import (PairTransformTrain, PairTransformValid, Shuffled2DPaired, ensure_3ch,
+                                                     paired_random_crop)
+    make_dataset(str(tmp_path))
+    ds = Shuffled2DPaired(str(tmp_path), split="train", scale="X4", transform_pair=PairTransformTrain(64, 4))
+    assert len(ds) == 6
+    random.seed(1)
+    lr, hr = ds[0]
+    assert lr.shape == (3, 64, 64) and hr.shape == (3, 256, 256) and lr.dtype == torch.float32
+    assert 0.0 <= float(lr.min()) and float(lr.max()) <= 1.0
+    vlr, vhr = Shuffled2DPaired(str(tmp_path), split="valid", scale="X4", transform_pair=PairTransformValid(4))[1]
+    assert vlr.shape == (3, 72, 72) and vhr.shape == (3, 288, 288)
+    # crop alignment: HR crop starts at (top*scale, left*scale)   (finetune_swinir.py:96-110)
+    a = torch.arange(10 * 12, dtype=torch.float32).reshape(1, 10, 12)
+    b = a.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    random.seed(3)
+    ca, cb = paired_random_crop(a, b, 4, 2)
+    assert torch.equal(cb[:, ::2, ::2], ca)
+    with pytest.raises(ValueError):
+        paired_random_crop(a, b, 64, 2)
+    with pytest.raises(ValueError):
+        ensure_3ch(torch.zeros(2, 4, 4))
+    with pytest.raises(FileNotFoundError):
+        Shuffled2DPaired(str(tmp_path), split="test", scale="X4")
+
+
+@pytest.mark.gpu
+def test_finetune_script_one_epoch(tmp_path, capsys, monkeypatch):
+    from tpu_superresolution_amd import finetune_swinir as F
+    make_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    F.main(["--data_root", str(tmp_path), "--scale", "X4", "--epochs", "2", "--batch_size", "2", "--workers", "0", "--lr", "1e-4"])
+    out = capsys.readouterr().out
+    assert "[X4] epoch 001/2" in out and "[done] best_val_loss=" in out
+    ck = torch.load(tmp_path / "best_swinir_finetune_X4.pt", map_location="cpu", weights_only=False)
+    assert set(ck) >= {"model", "epoch", "best_val_loss", "val_psnr", "args"}
+    assert len(ck["model"]) == 550 and not any(k.startswith("module.") for k in ck["model"])
+    # the saved state_dict loads back (strict) through the {"params": ...} envelope of public SwinIR checkpoints
+    torch.save({"params": ck["model"]}, tmp_path / "w.pth")
+    F.main(["--data_root", str(tmp_path), "--scale", "X4", "--epochs", "1", "--batch_size", "2", "--workers", "0",
+            "--weights", str(tmp_path / "w.pth"), "--freeze_regex", "conv_first|layers\\.0"])
+    assert "[weights] missing=0, unexpected=0" in capsys.readouterr().out
