@@ -10,7 +10,8 @@ Weak scaling: every rank processes its own 32 patches.
 
 Extra legs (rank 0, N=1):
   roofline     -- HIP-event timing of the dominant kernel family (the linear-layer MFMA GEMM) bracketed
-                  inside the timed steps by libsrk's probe; achieved = algorithmic FLOPs / kernel time.
+                  inside the timed steps by libsrk's probe; achieved = algorithmic bytes / kernel time (HBM-bound
+                  family), with the MFMA view alongside.
   cpu_baseline -- the CPU oracle (oracle/swinir_oracle.py, a port of the reference) running the same
                   train step at batch 2 on the host cores.
 """
@@ -31,6 +32,7 @@ sys.path.insert(0, ROOT)
 HR_PX_PER_SAMPLE = 256 * 256
 FLOP_PER_IMAGE_TRAIN = 321.299e9      # fwd+bwd algorithmic FLOPs per 64x64 LR image
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0                # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy ceiling)
 
 
 def synthetic_batch(batch, device, seed):
@@ -44,7 +46,12 @@ def synthetic_batch(batch, device, seed):
 def cpu_baseline(steps=3, batch=2, threads=None):
     """Reference algorithm (CPU oracle, fp32) on the host cores: same train step, bounded sample."""
     from oracle import swinir_oracle as O
-    threads = threads or max(1, min(os.cpu_count() or 1, 64))
+    if threads is None:
+        try:
+            avail = len(os.sched_getaffinity(0))          # the box's CPU share, not the host's core count
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        threads = int(os.environ.get("SRK_CPU_BASELINE_THREADS", max(1, min(avail, 32))))
     torch.set_num_threads(threads)
     cfg = O.SwinIRConfig.classical_x4()
     state = O.TrainState(sd=O.random_state_dict(cfg, 42, 1.5))
@@ -116,14 +123,23 @@ def main():
     elapsed = time.perf_counter() - t0
     roof = None
     if probe:
-        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
-        _lib.check(lib.srk_probe_end(C.byref(ms), C.byref(fl), C.byref(n)))
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _lib.check(lib.srk_probe_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
         if n.value:
-            achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_kernel<LD_ROWS,*> (linear layers fwd+dgrad)", "achieved": achieved,
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                    "launches": n.value, "avg_launch_us": 1e3 * ms.value / n.value,
-                    "share_of_step": ms.value / (1e3 * elapsed)}
+            # The linear layers are skinny GEMMs (N, K <= 576): arithmetic intensity 100-150 FLOP/B sits left of the
+            # MI355X ridge (~310 FLOP/B), so with one launch per layer the family is HBM-bound, not MFMA-bound.
+            gbs = by.value / (ms.value * 1e-3) / 1e9
+            tfl = fl.value / (ms.value * 1e-3) / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_pmc_linear_gemm_traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf))["avg_hbm_bytes_per_launch"]      # rocprofv3 PMC, same workload
+            roof = {"bound": "hbm", "kernel": "gemm_kernel<LD_ROWS,*> (linear layers: qkv/proj/fc1/fc2 forward and dgrad, with "
+                                               "their fused bias/GELU/residual/LayerNorm epilogues)",
+                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value,
+                    "avg_launch_us": 1e3 * ms.value / n.value, "share_of_step": ms.value / (1e3 * elapsed),
+                    "mfma": {"achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS}}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:

@@ -92,9 +92,10 @@ int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream);
 /* Timing probe for the roofline leg of bench.py: while a probe is active every launch of the chosen kernel
  * family (1 linear GEMM, 2 conv GEMM, 3 linear wgrad, 4 conv wgrad, 5 attention fwd, 6 attention bwd) is bracketed
  * by HIP events on its own stream.  srk_probe_end synchronises those events and returns the summed kernel time,
- * the summed ALGORITHMIC (un-padded) FLOPs and the launch count.  Not thread-safe; one probe at a time. */
+ * the summed ALGORITHMIC (un-padded) FLOPs and HBM bytes (each operand read / result written once) and the
+ * launch count.  Not thread-safe; one probe at a time. */
 int srk_probe_begin(int family, int capacity);
-int srk_probe_end(double* total_ms, double* flops, int* launches);
+int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches);
 
 /* ---- training-step pieces  (finetune_swinir.py:148-179) ------------------------------------------ */
 /* F.l1_loss(pred, target) (:66-67, :163) forward + backward in one pass; also counts non-finite pred

@@ -62,7 +62,7 @@ _SIGNATURES = {
     "srk_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "srk_probe_trread": (_i, [_vp, _vp, _vp]),
     "srk_probe_begin": (_i, [_i, _i]),
-    "srk_probe_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "srk_probe_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "srk_l1_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
     "srk_grad_sumsq": (_i, [_vp, _i64, _vp, _vp]),
     "srk_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp]),

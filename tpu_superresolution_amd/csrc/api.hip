@@ -30,15 +30,16 @@ struct Probe {
   int family = 0;
   bool active = false;
   size_t count = 0;
-  double flops = 0.0;
+  double flops = 0.0, bytes = 0.0;
   std::vector<hipEvent_t> ev0, ev1;
 } g_probe;
 }  // namespace
 
-void srk_probe_pre(int family, hipStream_t stream, double flops) {
+void srk_probe_pre(int family, hipStream_t stream, double flops, double bytes) {
   if (!g_probe.active || family != g_probe.family || g_probe.count >= g_probe.ev0.size()) return;
   hipEventRecord(g_probe.ev0[g_probe.count], stream);
   g_probe.flops += flops;
+  g_probe.bytes += bytes;
 }
 
 void srk_probe_post(int family, hipStream_t stream) {
@@ -207,11 +208,12 @@ int srk_probe_begin(int family, int capacity) {
   g_probe.family = family;
   g_probe.count = 0;
   g_probe.flops = 0.0;
+  g_probe.bytes = 0.0;
   g_probe.active = true;
   return SRK_OK;
 }
 
-int srk_probe_end(double* total_ms, double* flops, int* launches) {
+int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches) {
   SRK_REQUIRE(g_probe.active, SRK_E_STATE, "probe_end: no active probe");
   g_probe.active = false;
   double ms = 0.0;
@@ -225,6 +227,7 @@ int srk_probe_end(double* total_ms, double* flops, int* launches) {
   }
   if (total_ms) *total_ms = ms;
   if (flops) *flops = g_probe.flops;
+  if (bytes) *bytes = g_probe.bytes;
   if (launches) *launches = (int)g_probe.count;
   return SRK_OK;
 }

@@ -21,7 +21,7 @@ int srk_check_launch(const char* what);
 // optional per-launch timing probe (bench.py roofline leg): HIP events around launches of one kernel family
 enum { FAM_GEMM_LINEAR = 1, FAM_GEMM_CONV = 2, FAM_WGRAD_LINEAR = 3, FAM_WGRAD_CONV = 4, FAM_ATTN_FWD = 5, FAM_ATTN_BWD = 6,
        FAM_LN = 7 };
-void srk_probe_pre(int family, hipStream_t stream, double flops);
+void srk_probe_pre(int family, hipStream_t stream, double flops, double bytes = 0.0);
 void srk_probe_post(int family, hipStream_t stream);
 
 #define SRK_REQUIRE(cond, code, ...)      \

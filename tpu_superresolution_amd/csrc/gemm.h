@@ -48,6 +48,7 @@ struct GemmParams {
   const float* res;    // fp32 residual
   const bf16_t* aux;   // bf16 auxiliary (pre-activation / activation sign)
   double flops;        // algorithmic (un-padded) FLOPs of this launch, for the timing probe
+  double bytes;        // algorithmic HBM bytes of this launch (every operand read / result written once, un-padded)
   int ldo;             // row stride (elements) of outf/outb/res/aux
   float scale;         // EP_QKV q scale; EP_LRELU/EP_DLRELU slope
   int nH, CA;          // EP_QKV: heads and nH*32

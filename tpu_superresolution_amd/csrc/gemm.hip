@@ -285,7 +285,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
   }
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN));
   const int fam = LD == LD_ROWS ? FAM_GEMM_LINEAR : FAM_GEMM_CONV;
-  srk_probe_pre(fam, stream, p.flops);
+  srk_probe_pre(fam, stream, p.flops, p.bytes);
   hipLaunchKernelGGL((gemm_kernel<LD, EP, NT, NARROW>), grid, dim3(256), lds, stream, p);
   srk_probe_post(fam, stream);
   return srk_check_launch("gemm");

@@ -600,6 +600,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         g.A = c.at<bf16_t>(ba.xn1w); g.lda = CP; g.Wt = c.packed + bw.Wqkv; g.M = T; g.N = 3 * bw.CA; g.K = CP;
         g.bias = c.side + bw.bqkv; g.outb = c.at<bf16_t>(ba.qkv); g.scale = bw.scale; g.nH = bw.nH; g.CA = bw.CA; g.B_ = T / 64;
         g.flops = fl_qkv;
+        g.bytes = (double)T * (2.0 * C + 6.0 * C) + 6.0 * C * C;                 // xn1 in, q/k/v out, weights once
         RUN(srk_launch_gemm(LD_ROWS, EP_QKV, g, st));
       }
       // softmax(qk^T + bias + mask) v                :125-142
@@ -609,6 +610,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         g.A = c.at<bf16_t>(ba.ao); g.lda = bw.CA; g.Wt = c.packed + bw.Wproj; g.M = T; g.N = CP; g.K = bw.CA;
         g.bias = c.side + bw.bproj; g.res = c.at<float>(ba.x_in); g.outf = c.at<float>(ba.x1); g.ldo = CP; g.geom = geom;
         g.rowscale = ds_attn; g.rows_per_sample = HW; g.flops = fl_proj;
+        g.bytes = (double)T * (2.0 * C + 4.0 * C + 4.0 * C + (fuse_ln ? 2.0 * C + 8 : 0)) + 2.0 * C * C;   // ao, x in; x1 (+xn2) out
         if (fuse_ln) {   // LN2 (:277) of the row just written, fused into the epilogue
           g.xn_out = c.at<bf16_t>(ba.xn2); g.xn_mean = c.at<float>(ba.mean2); g.xn_rstd = c.at<float>(ba.rstd2);
           g.xn_gamma = params + bw.n2w; g.xn_beta = params + bw.n2b; g.xn_C = C; g.xn_window = 0;
@@ -622,6 +624,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.xn2); g.lda = CP; g.Wt = c.packed + bw.Wfc1; g.M = T; g.N = HP; g.K = CP;
         g.bias = c.side + bw.bfc1; g.outb = c.at<bf16_t>(ba.u); g.outb2 = c.at<bf16_t>(ba.h); g.ldo = HP; g.flops = fl_mlp;
+        g.bytes = (double)T * (2.0 * C + 4.0 * p->HID) + 2.0 * C * p->HID;           // xn2 in; u, h out
         RUN(srk_launch_gemm(LD_ROWS, EP_GELU, g, st));
       }
       {  // fc2 + residual                             :28, :277
@@ -630,6 +633,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         g.bias = c.side + bw.bfc2; g.res = c.at<float>(ba.x1); g.outf = c.at<float>(ba.x_out); g.ldo = CP;
         g.outb = (j == depth - 1) ? c.at<bf16_t>(w.layer_xb[l]) : nullptr;
         g.rowscale = ds_mlp; g.rows_per_sample = HW; g.flops = fl_mlp;
+        g.bytes = (double)T * (2.0 * p->HID + 4.0 * C + 4.0 * C + 2.0 * C) + 2.0 * C * p->HID;   // h, x1 in; x2 + (xb | next xn1) out
         if (fuse_ln && j + 1 < depth) {   // next block's norm1 (+ its roll + window partition) fused into this epilogue
           const BlockW& nb = p->blocks[bi + 1];
           const BlockAct& na = w.blk[bi + 1];
@@ -838,6 +842,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gxb2); g.lda = CP; g.Wt = c.packed + bw.Wfc2T; g.M = T; g.N = HP; g.K = CP;
           g.outb = c.at<bf16_t>(w.du); g.aux = c.at<bf16_t>(ba.u); g.ldo = HP; g.flops = fl_mlp;
+          g.bytes = (double)T * (2.0 * C + 2.0 * p->HID + 2.0 * p->HID) + 2.0 * C * p->HID;   // d x2, u in; d u out
           RUN(srk_launch_gemm(LD_ROWS, EP_DGELU, g, st));
         }
         WgradParams wq[4];   // the four weight gradients of the block go out as one launch (before gxb2 is overwritten)
@@ -846,6 +851,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.du); g.lda = HP; g.Wt = c.packed + bw.Wfc1T; g.M = T; g.N = CP; g.K = HP;
           g.ldo = CP; g.flops = fl_mlp;
+          g.bytes = (double)T * (2.0 * p->HID + 4.0 * C + 8.0 * C + 2.0 * C) + 2.0 * C * p->HID;   // d u, x1, gx in; gx, gxbw out
           if (fuse_ln) {   // ... with LN2 backward fused into the epilogue: gx2 += dx1, gxbw = bf16(gx2 * f_attn) in window order
             g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxbw); g.geom = geom; g.rowscale = ds_attn; g.rows_per_sample = HW;
             g.ln_x = c.at<float>(ba.x1); g.ln_mean = c.at<float>(ba.mean2); g.ln_rstd = c.at<float>(ba.rstd2);
@@ -867,7 +873,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         {  // d attn_out = d x1(window order) . Wproj
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gxbw); g.lda = CP; g.Wt = c.packed + bw.WprojT; g.M = T; g.N = bw.CA; g.K = CP;
-          g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA; g.flops = fl_proj;
+          g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA; g.flops = fl_proj; g.bytes = (double)T * 4.0 * C + 2.0 * C * C;
           RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
         }
         wq[2] = lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj, fl_proj);
@@ -879,6 +885,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.dqkv); g.lda = 3 * bw.CA; g.Wt = c.packed + bw.WqkvT; g.M = T; g.N = CP; g.K = 3 * bw.CA;
           g.ldo = CP; g.flops = fl_qkv;
+          g.bytes = (double)T * (6.0 * C + 4.0 * C + 8.0 * C + 2.0 * C) + 6.0 * C * C;   // d qkv, x, gx in; gx, gxb2 out
           if (fuse_ln) {   // ... with LN1 backward (+ window reverse + un-roll) fused: gx2[tok] += dx, gxb2 = bf16(gx2 * f_mlp(prev))
             g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxb2); g.geom = geom; g.rowscale = ds_prev_mlp; g.rows_per_sample = HW;
             g.ln_x = c.at<float>(ba.x_in); g.ln_mean = c.at<float>(ba.mean1); g.ln_rstd = c.at<float>(ba.rstd1);

@@ -15,6 +15,7 @@ struct WgradParams {
   int conv;          // 0 linear, 1 conv3x3
   int B, H, W;       // conv geometry
   double flops;      // algorithmic (un-padded) FLOPs of this launch, for the timing probe
+  double bytes;      // algorithmic HBM bytes of this launch
   int r, Cs;         // conv: Y stored pixel-shuffled with factor r, Cs stored channels (r <= 1: plain)
 };
 

@@ -191,12 +191,13 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   WgradMulti mp;
   mp.nprob = nprob;
   int tiles = 0;
-  double flops = 0.0;
+  double flops = 0.0, bytes = 0.0;
   for (int i = 0; i < nprob; ++i) {
     mp.p[i] = ps[i];
     mp.tile_begin[i] = tiles;
     tiles += (ps[i].N / (64 * TA)) * (ps[i].K / (64 * TB)) * (CONV ? 9 : 1);
     flops += ps[i].flops;
+    bytes += ps[i].bytes;
   }
   mp.tile_begin[nprob] = tiles;
   // one workgroup per CU (LDS-limited): aim at ~256 workgroups; every split costs one pass of fp32 atomics over dW
@@ -208,7 +209,7 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   mp.m_per = m_per;
   splits = cdiv(M, m_per);
   const int fam = CONV ? FAM_WGRAD_CONV : FAM_WGRAD_LINEAR;
-  srk_probe_pre(fam, stream, flops);
+  srk_probe_pre(fam, stream, flops, bytes);
   hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles * splits), dim3(256), lds, stream, mp);
   srk_probe_post(fam, stream);
   return srk_check_launch("wgrad");
