@@ -136,72 +136,94 @@ __device__ __forceinline__ void load_bias_T(f32x4_t (&bias)[4][4], const float* 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// One 4-wave workgroup owns one (window, head) at a time; wave w handles the 16 queries of tile it = w against all
+// 64 keys (4 + 4 MFMAs).  K and V are staged once per window in LDS (V is read back transposed); the next window's
+// tiles are prefetched into registers.  ~64 VGPRs and 10 KB of LDS per workgroup -> up to 8 workgroups per CU.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
                                                        bf16_t* __restrict__ ao, long long B_, int nH, int CA,
                                                        WinGeom geom, int wpw) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[4][64 * TS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * TS], Vs[64 * TS];
+  const int tid = threadIdx.x, lane = tid & 63, it = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y;
-  bf16_t* Vs = lds[wave];
-  const long long w_begin = ((long long)blockIdx.x * 4 + wave) * wpw;
+  const long long w_begin = (long long)blockIdx.x * wpw;
+  const int srow = tid >> 2, sch = tid & 3;
+  const float* bias_h = biasd + h * 4096;
 
-  BiasRegs bias;
-  load_bias_T(bias.v, biasd, h, lane);
+  uint4 prek = make_uint4(0, 0, 0, 0), prev = prek, preq = prek;
+#define ATTN_FWD_PREFETCH(BW)                                                                                  \
+  do {                                                                                                         \
+    prek = *reinterpret_cast<const uint4*>(qkv + ((1 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);     \
+    prev = *reinterpret_cast<const uint4*>(qkv + ((2 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);     \
+    preq = *reinterpret_cast<const uint4*>(qkv + ((0 * B_ + (BW)) * nH + h) * 2048 + (16 * it + r16) * 32 + 8 * g); \
+  } while (0)
+  if (w_begin < B_) ATTN_FWD_PREFETCH(w_begin);
 
   for (int wi = 0; wi < wpw; ++wi) {
     const long long b_ = w_begin + wi;
     if (b_ >= B_) break;
-    const bf16_t* Q = qkv + ((0 * B_ + b_) * nH + h) * 2048;
-    const bf16_t* K = qkv + ((1 * B_ + b_) * nH + h) * 2048;
-    const bf16_t* V = qkv + ((2 * B_ + b_) * nH + h) * 2048;
-    stage_tile_64x32(Vs, V, 32, lane);
+    *reinterpret_cast<uint4*>(Ks + srow * TS + sch * 8) = prek;
+    *reinterpret_cast<uint4*>(Vs + srow * TS + sch * 8) = prev;
+    const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, preq);
+    __syncthreads();
+    if (wi + 1 < wpw && b_ + 1 < B_) ATTN_FWD_PREFETCH(b_ + 1);
 
-    bf16x8_t kf[4], qf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      kf[t] = *reinterpret_cast<const bf16x8_t*>(K + (16 * t + r16) * 32 + 8 * g);
-      qf[t] = *reinterpret_cast<const bf16x8_t*>(Q + (16 * t + r16) * 32 + 8 * g);
-    }
-    f32x4_t s[4][4];
+    f32x4_t s[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
+      s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, TS, 16 * jt + r16, 8 * g), qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    {
+      const int w = (int)b_ % geom.nW;
+      const int wy = w / geom.nWw, wx = w - wy * geom.nWw;
+      const bool masked = geom.shift > 0 && (wy == geom.H / 8 - 1 || wx == geom.nWw - 1);
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
-        s[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-
-    softmax_T(s, bias, geom, (int)(b_ % geom.nW), lane);
-
-    __builtin_amdgcn_wave_barrier();
-    f32x4_t o[2][4];
+      for (int jt = 0; jt < 4; ++jt) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_h + (16 * it + r16) * 64 + 16 * jt + 4 * g);
+        s[jt] += f32x4_t{bv.x, bv.y, bv.z, bv.w};
+      }
+      if (masked) {
+        const int labi = win_region_label(geom, w, 16 * it + r16);
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) o[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e)
+            if (win_region_label(geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
+      mx = xmax4(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[jt][e] = __expf(s[jt][e] - mx);
+          sum += s[jt][e];
+        }
+      const float inv = 1.0f / xsum4(sum);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[jt][e] *= inv;
+    }
+    f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      bf16x8_t vf[2];
+      const uint2 lo = pack_bf4(s[2 * ss][0], s[2 * ss][1], s[2 * ss][2], s[2 * ss][3]);
+      const uint2 hi = pack_bf4(s[2 * ss + 1][0], s[2 * ss + 1][1], s[2 * ss + 1][2], s[2 * ss + 1][3]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) vf[dt] = tr_frag_acc(Vs, TS, 32 * ss, 16 * dt, lane);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const uint2 lo = pack_bf4(s[2 * ss][it][0], s[2 * ss][it][1], s[2 * ss][it][2], s[2 * ss][it][3]);
-        const uint2 hi = pack_bf4(s[2 * ss + 1][it][0], s[2 * ss + 1][it][1], s[2 * ss + 1][it][2], s[2 * ss + 1][it][3]);
-        const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf, o[dt][it], 0, 0, 0);
-      }
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_acc(Vs, TS, 32 * ss, 16 * dt, lane), pf, o[dt], 0, 0, 0);
     }
-    // o[dt][it][e] = O[i = 16it + r16][d = 16dt + 4g + e]
+    // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]
+    bf16_t* dst = ao + (b_ * 64 + 16 * it + r16) * CA + h * 32 + 4 * g;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        bf16_t* dst = ao + (b_ * 64 + 16 * it + r16) * CA + h * 32 + 16 * dt + 4 * g;
-        *reinterpret_cast<uint2*>(dst) = pack_bf4(o[dt][it][0], o[dt][it][1], o[dt][it][2], o[dt][it][3]);
-      }
-    __builtin_amdgcn_wave_barrier();
+    for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<uint2*>(dst + 16 * dt) = pack_bf4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    __syncthreads();
   }
 }
 
@@ -385,10 +407,14 @@ __global__ void rpb_expand_kernel(const float* __restrict__ table, float* __rest
 
 int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long long B_, int nH, WinGeom geom,
                         hipStream_t stream) {
-  const int wpw = B_ >= 4096 ? 4 : 1;
-  dim3 grid((unsigned)((B_ + 4 * wpw - 1) / (4 * wpw)), nH);
+  // windows per workgroup: as few as possible while every workgroup is resident at once (8 per CU)
+  const long long slots = 8 * 256;
+  long long wpw = (B_ * nH + slots - 1) / slots;
+  if (wpw < 1) wpw = 1;
+  while (((B_ + wpw - 1) / wpw) * nH > slots && wpw < B_) ++wpw;
+  dim3 grid((unsigned)((B_ + wpw - 1) / wpw), nH);
   srk_probe_pre(FAM_ATTN_FWD, stream, 0.0);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, qkv, biasd, ao, B_, nH, nH * 32, geom, wpw);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, qkv, biasd, ao, B_, nH, nH * 32, geom, (int)wpw);
   srk_probe_post(FAM_ATTN_FWD, stream);
   return srk_check_launch("attn_fwd");
 }

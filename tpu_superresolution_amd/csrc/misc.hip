@@ -349,7 +349,7 @@ __global__ void img_grad_prep_kernel(const float* __restrict__ dpred, float* __r
 // dX[pix][ci] = sum_tap sum_co gy[pix - off(tap)][co] * W[co][ci][tap]  -> bf16 NHWC [pix][CinP]
 __global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wgt,
                                                               bf16_t* __restrict__ dx, int B, int H, int W, int Cin,
-                                                              int CinP, int Co, int CoP) {
+                                                              int CinP, int Co, int CoP, int groups) {
   extern __shared__ float sm[];
   float* wl = sm;                       // [9][Co][CinP]
   float* gl = sm + 9 * Co * CinP;       // [16 pixels][9][CoP]
@@ -358,7 +358,10 @@ __global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float* __res
     wl[i] = ci < Cin ? wgt[((co * Cin) + ci) * 9 + tap] : 0.f;
   }
   const long long npix = (long long)B * H * W;
-  const long long pix0 = (long long)blockIdx.x * 16;
+  for (int grp = 0; grp < groups; ++grp) {     // the staged weights are reused for `groups` x 16 pixels
+  const long long pix0 = ((long long)blockIdx.x * groups + grp) * 16;
+  if (pix0 >= npix) break;
+  __syncthreads();
   for (int i = threadIdx.x; i < 16 * 9 * CoP; i += 256) {
     const int n = i % CoP, tap = (i / CoP) % 9, pp = i / (9 * CoP);
     const long long pix = pix0 + pp;
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float* __res
         a0 += g * wv.x; a1 += g * wv.y; a2 += g * wv.z; a3 += g * wv.w;
       }
     *reinterpret_cast<uint2*>(dx + pix * CinP + c4) = pack_bf4(a0, a1, a2, a3);
+  }
   }
 }
 
@@ -682,8 +686,9 @@ int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, in
   const size_t lds = (size_t)(9 * Co * CinP + 16 * 9 * CoP) * sizeof(float);
   SRK_REQUIRE(lds <= 64 * 1024, SRK_E_SHAPE, "smallconv dgrad: LDS %zu too large", lds);
   const long long npix = (long long)B * H * W;
-  hipLaunchKernelGGL(smallconv_dgrad_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), lds, stream, gy, wgt, dx, B, H,
-                     W, Cin, CinP, Co, CoP);
+  const int groups = npix >= (1 << 20) ? 32 : 4;
+  hipLaunchKernelGGL(smallconv_dgrad_kernel, dim3((unsigned)((npix + 16 * groups - 1) / (16 * groups))), dim3(256), lds, stream,
+                     gy, wgt, dx, B, H, W, Cin, CinP, Co, CoP, groups);
   return srk_check_launch("smallconv_dgrad");
 }
 
