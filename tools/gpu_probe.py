@@ -116,3 +116,24 @@ if __name__ == "__main__":
         grads()
     if what in ("timing", "all"):
         timing()
+
+
+def infer_timing():
+    for tag, cfg, bs, hw in (("cfg2 SwinIR-light x2", O.SwinIRConfig.light_x2(), 16, 48), ("cfg3 SwinIR x4 (fwd only)", O.SwinIRConfig.classical_x4(), 32, 64)):
+        m = build(cfg, O.random_state_dict(cfg, 42, 1.0))
+        x = torch.rand(bs, 3, hw, hw, device="cuda")
+        with torch.no_grad():
+            for _ in range(3):
+                m(x)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            n = 20
+            for _ in range(n):
+                y = m(x)
+            torch.cuda.synchronize()
+        dt = (time.time() - t0) / n
+        print(f"{tag}: bs{bs} {hw}x{hw} forward {1e3*dt:.2f} ms -> {bs * (hw * cfg.upscale) ** 2 / dt / 1e6:.1f} M HR px/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "infer":
+    infer_timing()
