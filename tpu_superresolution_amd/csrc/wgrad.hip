@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
   while (pi + 1 < mp.nprob && btile >= mp.tile_begin[pi + 1]) ++pi;
   const WgradParams& p = mp.p[pi];
   constexpr int TN = 64 * TA, TK = 64 * TB;
-  constexpr int SY = TN + 8, SX = TK + 8;          // LDS row strides (elements)
+  constexpr int SY = TN + 16, SX = TK + 16;        // LDS row strides: 32 B x odd -> the 8 rows a half-wave
+                                                   // tr-reads (below) fall in 8 disjoint bank windows: conflict-free
   constexpr int PY = (64 * TN / 8) / 256;          // 16-B pieces per thread
   constexpr int PX = (64 * TK / 8) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -133,15 +134,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
         const int c0 = wn * (32 * TA) + 16 * i;
-        const bf16x4_t lo = lds_tr_read(tr_addr(ys, SY, 32 * ks + 8 * g, c0, lane));
-        const bf16x4_t hi = lds_tr_read(tr_addr(ys, SY, 32 * ks + 8 * g + 4, c0, lane));
+        // k order inside the fragment: jj<4 -> m = 32ks + 4g + jj, jj>=4 -> m = 32ks + 16 + 4g + jj-4 (same for Y and X,
+        // so the product is unchanged); a 32-lane half then reads 8 CONSECUTIVE rows per instruction
+        const bf16x4_t lo = lds_tr_read(tr_addr(ys, SY, 32 * ks + 4 * g, c0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(ys, SY, 32 * ks + 16 + 4 * g, c0, lane));
         yf[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
       for (int j = 0; j < KTW; ++j) {
         const int c0 = wk * (32 * TB) + 16 * j;
-        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SX, 32 * ks + 8 * g, c0, lane));
-        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SX, 32 * ks + 8 * g + 4, c0, lane));
+        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SX, 32 * ks + 4 * g, c0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SX, 32 * ks + 16 + 4 * g, c0, lane));
         xf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
 
 template <int TA, int TB, bool CONV>
 int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
-  constexpr size_t lds = (size_t)2 * 64 * ((64 * TA + 8) + (64 * TB + 8)) * sizeof(bf16_t);
+  constexpr size_t lds = (size_t)2 * 64 * ((64 * TA + 16) + (64 * TB + 16)) * sizeof(bf16_t);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, TB, CONV>),
