@@ -184,3 +184,19 @@ def test_unsupported_scale_raises_like_reference():
     cfg = O.SwinIRConfig(upscale=5, upsampler="pixelshuffle", **TINY)
     with pytest.raises(ValueError, match="scale 5 is not supported"):
         O.state_dict_schema(cfg)
+
+
+def test_bf16_emulation_stays_within_bf16_noise_of_the_fp32_oracle():
+    """oracle/bf16_emulation.py is the fp32 oracle plus rounding hooks: it must stay within bf16 noise of the
+    golden fp32 outputs and gradients (it is the tighter checker of tests/test_gpu_emulation.py)."""
+    from oracle import bf16_emulation as E
+    g, cfg, sd = tiny_weights("ps4")
+    x, t = torch.from_numpy(g["train.x"]), torch.from_numpy(g["train.target"])
+    loss, out, grads = E.loss_and_grads_emul(sd, cfg, x, t)
+    assert abs(float(loss) - float(g["train.loss"])) <= 2e-3 * float(g["train.loss"])
+    rels = [float((grads[k] - torch.from_numpy(g["grad." + k])).norm() / (torch.from_numpy(g["grad." + k]).norm() + 1e-12)) for k in grads]
+    assert max(rels) <= 0.1 and float(np.median(rels)) <= 0.04
+    with torch.no_grad():
+        y = E.swinir_forward_emul(sd, cfg, torch.from_numpy(g["x_13x19"]))
+    ref = torch.from_numpy(g["y_13x19"])
+    assert y.shape == ref.shape and float((y - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
