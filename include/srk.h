@@ -97,6 +97,12 @@ int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream);
 int srk_probe_begin(int family, int capacity);
 int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches);
 
+/* Kernel-selection switches (A/B testing; results are equivalent up to fp32 summation order).
+ *   "gemm_stream" 1 (default) / 0: use the persistent LDS-DMA GEMM (csrc/gemm_stream.hip) for the block GEMMs it
+ *   covers, or always the tile-per-workgroup GEMM (csrc/gemm.hip).  Env SRK_GEMM_STREAM=0 sets the initial value.
+ * Unknown names return SRK_E_UNSUPPORTED. */
+int srk_set_option(const char* name, int value);
+
 /* ---- training-step pieces  (finetune_swinir.py:148-179) ------------------------------------------ */
 /* F.l1_loss(pred, target) (:66-67, :163) forward + backward in one pass; also counts non-finite pred
  * values (assert_finite :133-143, :164).  loss (fp32 scalar) and nonfinite (uint32) are ACCUMULATED

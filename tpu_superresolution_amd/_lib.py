@@ -61,6 +61,7 @@ _SIGNATURES = {
     "srk_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srk_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "srk_probe_trread": (_i, [_vp, _vp, _vp]),
+    "srk_set_option": (_i, [C.c_char_p, _i]),
     "srk_probe_begin": (_i, [_i, _i]),
     "srk_probe_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "srk_l1_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),

@@ -2,6 +2,7 @@
 // kernel launchers.  No torch types, no allocation, no synchronisation.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "kernels.h"
 
@@ -230,6 +231,16 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
   if (bytes) *bytes = g_probe.bytes;
   if (launches) *launches = (int)g_probe.count;
   return SRK_OK;
+}
+
+int srk_set_option(const char* name, int value) {
+  REQ_PTR(name);
+  if (strcmp(name, "gemm_stream") == 0) {
+    srk_gemm_stream_enable(value);
+    return SRK_OK;
+  }
+  srk_set_error("srk_set_option: unknown option '%s'", name);
+  return SRK_E_UNSUPPORTED;
 }
 
 int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream) {

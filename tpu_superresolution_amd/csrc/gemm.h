@@ -81,3 +81,8 @@ struct GemmParams {
 };
 
 int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t stream);
+
+// gemm_stream.hip: persistent LDS-DMA variant for the LD_ROWS block GEMMs; SRK_NOT_COVERED -> use the tile kernel
+#define SRK_NOT_COVERED 1
+int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream);
+void srk_gemm_stream_enable(int on);

@@ -318,6 +318,15 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
                 "gemm: fused LayerNorm output needs a residual epilogue and N in {64,128,192} (N=%d)", p.N);
     SRK_REQUIRE(p.xn_mean && p.xn_rstd && p.xn_gamma && p.xn_beta, SRK_E_NULL, "gemm: fused LayerNorm: null pointer");
   }
+  if (epilogue == EP_LNBWD) {
+    SRK_REQUIRE(loader == LD_ROWS && (p.N == 64 || p.N == 128 || p.N == 192), SRK_E_SHAPE, "gemm(ln-bwd epilogue): N=%d must be one tile (64/128/192)", p.N);
+    SRK_REQUIRE(p.ln_x && p.ln_mean && p.ln_rstd && p.ln_gamma && p.ln_dgamma && p.ln_dbeta && p.outf, SRK_E_NULL,
+                "gemm(ln-bwd epilogue): null pointer");
+  }
+  if (loader == LD_ROWS) {
+    const int rc = srk_launch_gemm_stream(epilogue, p, stream);
+    if (rc != SRK_NOT_COVERED) return rc;
+  }
 #define CASE(LD, EP) \
   if (loader == LD && epilogue == EP) return dispatch_nt<LD, EP>(p, stream);
   CASE(LD_ROWS, EP_BF16)
@@ -326,12 +335,7 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
   CASE(LD_ROWS, EP_GELU)
   CASE(LD_ROWS, EP_RES)
   CASE(LD_ROWS, EP_DGELU)
-  if (loader == LD_ROWS && epilogue == EP_LNBWD) {
-    SRK_REQUIRE(p.N == 64 || p.N == 128 || p.N == 192, SRK_E_SHAPE, "gemm(ln-bwd epilogue): N=%d must be one tile (64/128/192)", p.N);
-    SRK_REQUIRE(p.ln_x && p.ln_mean && p.ln_rstd && p.ln_gamma && p.ln_dgamma && p.ln_dbeta && p.outf, SRK_E_NULL,
-                "gemm(ln-bwd epilogue): null pointer");
-    return dispatch_nt<LD_ROWS, EP_LNBWD>(p, stream);
-  }
+  CASE(LD_ROWS, EP_LNBWD)
   CASE(LD_CONV3, EP_RES)
   CASE(LD_CONV3, EP_RES_BF16)
   CASE(LD_CONV3, EP_LRELU)

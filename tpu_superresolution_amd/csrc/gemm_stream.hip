@@ -1,0 +1,500 @@
+// Streaming (persistent) variant of the bf16 MFMA linear GEMM for the skinny transformer-block GEMMs
+//
+//   D[m][n] = sum_k A[m][k] * Wt[n][k]   (+ row epilogue),   K in {192, 384, 576},  N a multiple of 192
+//
+// These GEMMs have an arithmetic intensity of 100-150 FLOP/B -- below the MI355X ridge -- so the job is to keep
+// HBM streaming, not to feed the MFMA.  The tile-per-workgroup kernel (gemm.hip) serialises, per tile, a chain of
+// dependent memory round trips (K-loop prefetch -> LDS -> MFMA -> epilogue loads -> stores) and leaves the memory
+// system idle for most of it.  Here one 512-thread workgroup per CU walks a strided list of BM-row tiles for ONE
+// 192-column slice of W:
+//
+//   * the W slice lives in REGISTERS as MFMA fragments for the whole kernel (no per-tile W traffic at all);
+//   * waves 4-7 are LOADERS: every global read of the loop -- the A rows AND the epilogue's row operands (fp32
+//     residual rows, LayerNorm input + gradient-stream rows, bf16 pre-activations, per-row statistics) -- is an
+//     LDS-DMA (global_load_lds) into an R-deep ring of LDS slots, issued R-1 tiles ahead of its use and retired
+//     with a counted s_waitcnt vmcnt, so that >= 64 KB per CU is in flight at all times without costing VGPRs;
+//     their vmcnt counter sees only those DMAs (they never store), which makes the counted wait exact;
+//   * waves 0-3 are CONSUMERS: MFMA on the A slot (fragments read straight from the swizzled DMA image), the
+//     accumulators go through an LDS tile T and are re-read ROW-major (16 lanes per row, the layout of
+//     gemm_rowep.h) together with the row operands of the slot, then stored -- they never wait on vmcnt;
+//     with KS2 the loader waves also run the MFMA of the upper K half and add it into T (K = 576 / register cap);
+//   * two raw s_barriers per tile (three with KS2); LDS visibility by s_waitcnt lgkmcnt(0) before each barrier.
+//
+// The A slot image is [BM][K] bf16 row-major with the 16-byte chunk index XOR-swizzled by (row & 7).  An LDS-DMA
+// writes lane-linear (wave-uniform base + 16 * lane), so the swizzle is applied on the per-lane SOURCE address.
+#include <hip/hip_runtime.h>
+
+#include "gemm.h"
+#include "gemm_rowep.h"
+
+namespace {
+
+constexpr int SBN = 192;         // columns per workgroup
+constexpr int SBNP = SBN + 4;    // T row pitch in floats (conflict-free float4 writes from the MFMA layout)
+constexpr int NC = SBN / 64;     // float4 per lane per row in the row-major phase
+constexpr int LDS_BUDGET = 160 * 1024;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// LDS operations of this wave complete, then the workgroup barrier (no vmcnt drain: DMAs and stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int EP, int KC, int BM>
+struct StreamCfg {
+  static constexpr int K = 64 * KC;
+  static constexpr int NE32 = (EP == EP_PROJ_RES || EP == EP_RES) ? 1 : (EP == EP_LNBWD ? 2 : 0);   // fp32 row operands
+  static constexpr int NE16 = (EP == EP_DGELU) ? 1 : 0;                                              // bf16 row operands
+  static constexpr bool AUX = (EP == EP_PROJ_RES || EP == EP_RES || EP == EP_LNBWD);               // per-row scalars
+  static constexpr int A_BYTES = BM * K * 2;
+  static constexpr int E32_BYTES = BM * SBN * 4;
+  static constexpr int E16_BYTES = BM * SBN * 2;
+  static constexpr int AUX_BYTES = AUX ? 4 * 64 * 4 : 0;          // one 64-float array per loader wave
+  static constexpr int SLOT = A_BYTES + NE32 * E32_BYTES + NE16 * E16_BYTES + AUX_BYTES;
+  static constexpr int T_BYTES = BM * SBNP * 4;
+  static constexpr int RED_BYTES = (EP == EP_LNBWD) ? 2 * SBN * 4 : 0;
+  // DMA instructions per loader wave per tile (each loader wave moves a quarter of every operand image)
+  static constexpr int CPW_A = BM * (K / 8) / 4, NI_A = (CPW_A + 63) / 64;
+  static constexpr int CPW_E32 = BM * (SBN / 4) / 4, NI_E32 = (CPW_E32 + 63) / 64;
+  static constexpr int CPW_E16 = BM * (SBN / 8) / 4, NI_E16 = (CPW_E16 + 63) / 64;
+  static constexpr int P = NI_A + NE32 * NI_E32 + NE16 * NI_E16 + (AUX ? 1 : 0);
+  static constexpr int R_LDS = (LDS_BUDGET - T_BYTES - RED_BYTES) / SLOT;
+  static constexpr int R_CNT = 2 + 63 / P;                         // vmcnt is a 6-bit counter
+  static constexpr int R0 = R_LDS < R_CNT ? R_LDS : R_CNT;
+  static constexpr int R = R0 > 8 ? 8 : R0;
+  static constexpr int LDS = T_BYTES + RED_BYTES + R * SLOT;
+  static_assert(R >= 2, "streaming GEMM: ring too shallow for this tile");
+  static_assert(P * (R - 2) <= 63, "vmcnt overflow");
+};
+
+// ---- loader: all DMAs of one tile ------------------------------------------------------------
+template <int EP, int KC, int BM>
+__device__ __forceinline__ void stream_issue_tile(const GemmParams& p, int m0, int n0, unsigned slot, int lw, int lane) {
+  using C = StreamCfg<EP, KC, BM>;
+  constexpr int CRA = C::K / 8;
+#pragma unroll
+  for (int i = 0; i < C::NI_A; ++i) {
+    const int q = i * 64 + lane;
+    if (q < C::CPW_A) {
+      const int qq = lw * C::CPW_A + q;
+      const int row = qq / CRA, pos = qq - row * CRA;
+      const int c = pos ^ (row & 7);
+      glds16(p.A + (long long)(m0 + row) * p.lda + c * 8, __builtin_amdgcn_readfirstlane(slot + (lw * C::CPW_A + i * 64) * 16));
+    }
+  }
+  unsigned off = slot + C::A_BYTES;
+  if constexpr (C::NE32 > 0) {
+#pragma unroll
+    for (int e = 0; e < C::NE32; ++e) {
+      const float* base = (EP == EP_LNBWD) ? (e == 0 ? p.ln_x : p.outf) : p.res;
+#pragma unroll
+      for (int i = 0; i < C::NI_E32; ++i) {
+        const int q = i * 64 + lane;
+        if (q < C::CPW_E32) {
+          const int qq = lw * C::CPW_E32 + q;
+          const int row = qq / (SBN / 4), pos = qq - row * (SBN / 4);
+          const int m = m0 + row;
+          long long t = m;
+          if constexpr (EP == EP_PROJ_RES) t = win_row_to_token(p.geom, m);
+          if constexpr (EP == EP_LNBWD) t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
+          glds16(base + t * p.ldo + n0 + pos * 4, __builtin_amdgcn_readfirstlane(off + (lw * C::CPW_E32 + i * 64) * 16));
+        }
+      }
+      off += C::E32_BYTES;
+    }
+  }
+  if constexpr (C::NE16 > 0) {
+#pragma unroll
+    for (int i = 0; i < C::NI_E16; ++i) {
+      const int q = i * 64 + lane;
+      if (q < C::CPW_E16) {
+        const int qq = lw * C::CPW_E16 + q;
+        const int row = qq / (SBN / 8), pos = qq - row * (SBN / 8);
+        glds16(p.aux + (long long)(m0 + row) * p.ldo + n0 + pos * 8, __builtin_amdgcn_readfirstlane(off + (lw * C::CPW_E16 + i * 64) * 16));
+      }
+    }
+    off += C::E16_BYTES;
+  }
+  if constexpr (C::AUX) {
+    // array lw of the slot: LNBWD {mean, rstd, rowscale, -}; residual epilogues {rowscale, -, -, -}; a "-" (or a null
+    // rowscale) still issues one harmless load so that every loader wave retires the same number of DMAs per tile
+    if (lane < BM) {
+      const int m = m0 + lane;
+      long long t = m;
+      if constexpr (EP == EP_PROJ_RES) t = win_row_to_token(p.geom, m);
+      if constexpr (EP == EP_LNBWD) t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
+      const float* src = reinterpret_cast<const float*>(p.Wt) + lane;
+      if constexpr (EP == EP_LNBWD) {
+        const long long st = p.ln_stats_by_m ? m : t;
+        if (lw == 0) src = p.ln_mean + st;
+        if (lw == 1) src = p.ln_rstd + st;
+        if (lw == 2 && p.rowscale) src = p.rowscale + t / p.rows_per_sample;
+      } else {
+        if (lw == 0 && p.rowscale) src = p.rowscale + t / p.rows_per_sample;
+      }
+      glds4(src, __builtin_amdgcn_readfirstlane(off + lw * 256));
+    }
+  }
+}
+
+// ---- the kernel --------------------------------------------------------------------------------
+template <int EP, int KC, int BM, bool KS2>
+__global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, int nchunk, int groups_per_xcd) {
+  using C = StreamCfg<EP, KC, BM>;
+  constexpr int K = C::K, R = C::R, MF = BM / 16;
+  constexpr int KST = KS2 ? K / 64 : K / 32;          // 32-wide k-steps per MFMA wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* T = reinterpret_cast<float*>(smem);
+  float* colred = reinterpret_cast<float*>(smem + C::T_BYTES);
+  const unsigned smem_base = (unsigned)(size_t)smem;            // LDS byte address of the dynamic segment
+  constexpr int SLOTS_OFF = C::T_BYTES + C::RED_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // workgroup -> (W slice, tile list): siblings of one tile list (the slices that re-read the same A rows) sit on
+  // the same XCD (blockIdx % 8) and walk the tiles in lock step, so A comes from HBM once and from that L2 after
+  const int xcd = blockIdx.x & 7, sx = blockIdx.x >> 3;
+  const int chunk = sx % nchunk, gx = sx / nchunk;
+  if (gx >= groups_per_xcd) return;
+  const int n0 = chunk * SBN;
+  const int Gm = 8 * groups_per_xcd, gi = gx * 8 + xcd;
+  const int ntm = p.M / BM;
+  const int nt = gi < ntm ? (ntm - gi + Gm - 1) / Gm : 0;
+  if (nt == 0) return;
+
+  const bool mfma_wave = KS2 || wave < 4;
+  const int wn = wave & 3, kh = KS2 ? (wave >> 2) : 0;
+
+  // ---- W slice -> registers ---------------------------------------------------------------------
+  bf16x8_t wf[3][KST];
+  if (mfma_wave) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < KST; ++s)
+        wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(n0 + wn * 48 + 16 * j + r16) * K + (kh * KST + s) * 32 + g * 8);
+    // make the compiler retire these loads HERE: left alone it waits for them at their first use inside the tile
+    // loop, and that s_waitcnt vmcnt(0) would drain the loaders' DMA ring on every iteration
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < KST; ++s) asm volatile("" ::"v"(wf[j][s]));
+  }
+  if constexpr (EP == EP_LNBWD) {
+    for (int i = tid; i < 2 * SBN; i += 512) colred[i] = 0.f;
+  }
+
+  if (wave >= 4) {
+    // =================================== loader waves =============================================
+    const int lw = wave - 4;
+    for (int s = 0; s < R - 1 && s < nt; ++s)
+      stream_issue_tile<EP, KC, BM>(p, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane);
+    for (int t = 0; t < nt; ++t) {
+      // tile t has landed once at most the (R-2) tiles issued after it are outstanding
+      if (t + R - 2 < nt) wait_vmcnt<C::P*(R - 2)>(); else wait_vmcnt<0>();
+      lds_barrier();                                                                 // B1
+      if (t + R - 1 < nt)
+        stream_issue_tile<EP, KC, BM>(p, (gi + (t + R - 1) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((t + R - 1) % R) * C::SLOT, lw, lane);
+      if constexpr (KS2) {
+        const unsigned char* As = smem + SLOTS_OFF + (t % R) * C::SLOT;
+        f32x4_t acc[MF][3];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+#pragma unroll
+          for (int i = 0; i < MF; ++i) {
+            const int row = 16 * i + r16;
+            const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(As + row * (K * 2) + ((((KST + s) * 4 + g) ^ (row & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[i][j], 0, 0, 0);
+          }
+        lds_barrier();                                                               // Bm: lower half is in T
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            float4* tp = reinterpret_cast<float4*>(T + (16 * i + r16) * SBNP + wn * 48 + 16 * j + 4 * g);
+            float4 o = *tp;
+            o.x += acc[i][j][0]; o.y += acc[i][j][1]; o.z += acc[i][j][2]; o.w += acc[i][j][3];
+            *tp = o;
+          }
+      }
+      lds_barrier();                                                                 // B2
+    }
+  } else {
+    // =================================== consumer waves ===========================================
+    const int sub = g, j16 = r16;
+    float4 bias[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      bias[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (EP != EP_DGELU && EP != EP_LNBWD) {
+        if (p.bias) bias[c] = *reinterpret_cast<const float4*>(p.bias + n0 + 64 * c + 4 * j16);
+      }
+    }
+    float gm[NC][4], cg[NC][4], cb[NC][4];
+    if constexpr (EP == EP_LNBWD) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 64 * c + 4 * j16 + e;
+          gm[c][e] = n < p.ln_C ? p.ln_gamma[n] : 0.f;
+          cg[c][e] = 0.f;
+          cb[c][e] = 0.f;
+        }
+    }
+    const float invC = EP == EP_LNBWD ? 1.0f / (float)p.ln_C : 0.f;
+    float lg[NC][4], lb[NC][4];
+    if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
+      if (p.xn_out) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = 64 * c + 4 * j16 + e;
+            lg[c][e] = n < p.xn_C ? p.xn_gamma[n] : 0.f;
+            lb[c][e] = n < p.xn_C ? p.xn_beta[n] : 0.f;
+          }
+      }
+    }
+    const bool has_scale = p.rowscale != nullptr;
+
+    for (int t = 0; t < nt; ++t) {
+      const int m0 = (gi + t * Gm) * BM;
+      const unsigned char* slot = smem + SLOTS_OFF + (t % R) * C::SLOT;
+      lds_barrier();                                                                 // B1: tile t is in its slot
+      {
+        f32x4_t acc[MF][3];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+#pragma unroll
+          for (int i = 0; i < MF; ++i) {
+            const int row = 16 * i + r16;
+            const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(slot + row * (K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[i][j], 0, 0, 0);
+          }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            *reinterpret_cast<float4*>(T + (16 * i + r16) * SBNP + wn * 48 + 16 * j + 4 * g) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+      if constexpr (KS2) lds_barrier();                                              // Bm
+      lds_barrier();                                                                 // B2: T is complete
+
+      // ---- row-major epilogue: 16 lanes per row, lane j16 holds columns 64c + 4 j16 .. +3 -----------------
+      const unsigned char* e0 = slot + C::A_BYTES;
+      const float* auxf = reinterpret_cast<const float*>(slot + C::A_BYTES + C::NE32 * C::E32_BYTES + C::NE16 * C::E16_BYTES);
+#pragma unroll
+      for (int ps = 0; ps < MF; ++ps) {
+        const int lr = ps * 16 + wave * 4 + sub;
+        const int m = m0 + lr;
+        float4 v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          v[c] = *reinterpret_cast<const float4*>(T + lr * SBNP + 64 * c + 4 * j16);
+          v[c].x += bias[c].x; v[c].y += bias[c].y; v[c].z += bias[c].z; v[c].w += bias[c].w;
+        }
+        if constexpr (EP == EP_BF16) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+        } else if constexpr (EP == EP_QKV) {
+          const long long b_ = m >> 6;
+          const int tok = m & 63;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int n = n0 + 64 * c + 4 * j16;
+            const int which = n / p.CA, rem = n - which * p.CA;
+            const int h = rem >> 5, d = rem & 31;
+            const float s = which == 0 ? p.scale : 1.0f;
+            bf16_t* dst = p.outb + ((((long long)which * p.B_ + b_) * p.nH + h) * 64 + tok) * 32 + d;
+            *reinterpret_cast<uint2*>(dst) = pack_bf4(v[c].x * s, v[c].y * s, v[c].z * s, v[c].w * s);
+          }
+        } else if constexpr (EP == EP_GELU) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const long long o = (long long)m * p.ldo + n0 + 64 * c + 4 * j16;
+            *reinterpret_cast<uint2*>(p.outb + o) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+            *reinterpret_cast<uint2*>(p.outb2 + o) = pack_bf4(gelu_f(v[c].x), gelu_f(v[c].y), gelu_f(v[c].z), gelu_f(v[c].w));
+          }
+        } else if constexpr (EP == EP_DGELU) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const uint2 ua = *reinterpret_cast<const uint2*>(e0 + lr * (SBN * 2) + (64 * c + 4 * j16) * 2);
+            float u0, u1, u2, u3;
+            unpack_bf2(ua.x, u0, u1);
+            unpack_bf2(ua.y, u2, u3);
+            *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) =
+                pack_bf4(v[c].x * dgelu_f(u0), v[c].y * dgelu_f(u1), v[c].z * dgelu_f(u2), v[c].w * dgelu_f(u3));
+          }
+        } else if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
+          long long t_ = m;
+          if constexpr (EP == EP_PROJ_RES) t_ = win_row_to_token(p.geom, m);
+          const float f = has_scale ? auxf[lr] : 1.0f;
+          float4 o[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float4 rv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+            o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
+            *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + n0 + 64 * c + 4 * j16) = o[c];
+            if constexpr (EP == EP_RES) {
+              if (p.outb) *reinterpret_cast<uint2*>(p.outb + t_ * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w);
+            }
+          }
+          if (p.xn_out) fused_ln_row<NC>(p, o, t_, j16, lg, lb);
+        } else if constexpr (EP == EP_LNBWD) {
+          const long long t_ = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
+          const float mean = auxf[lr], rstd = auxf[64 + lr];
+          const float f = has_scale ? auxf[128 + lr] : 1.0f;
+          float xh[NC][4], dy[NC][4];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float4 xv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const float dv[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              dy[c][e] = dv[e];
+              xh[c][e] = 64 * c + 4 * j16 + e < p.ln_C ? (xs[e] - mean) * rstd : 0.f;
+              const float dg = dv[e] * gm[c][e];
+              s1 += dg;
+              s2 += dg * xh[c][e];
+            }
+          }
+          s1 = wave_sum16(s1) * invC;
+          s2 = wave_sum16(s2) * invC;
+          const long long ro = p.ln_out_window ? token_to_win_row(p.geom, (int)t_) : t_;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float4 old = *reinterpret_cast<const float4*>(e0 + C::E32_BYTES + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+            float o[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (64 * c + 4 * j16 + e < p.ln_C) {
+                o[e] += rstd * (dy[c][e] * gm[c][e] - s1 - xh[c][e] * s2);
+                cg[c][e] += dy[c][e] * xh[c][e];
+                cb[c][e] += dy[c][e];
+              }
+            }
+            *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + 64 * c + 4 * j16) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.outb)
+              *reinterpret_cast<uint2*>(p.outb + ro * p.ldo + 64 * c + 4 * j16) = pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f);
+          }
+        }
+      }
+    }
+    if constexpr (EP == EP_LNBWD) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(&colred[64 * c + 4 * j16 + e], cg[c][e]);
+          atomicAdd(&colred[SBN + 64 * c + 4 * j16 + e], cb[c][e]);
+        }
+    }
+  }
+  if constexpr (EP == EP_LNBWD) {
+    // dgamma / dbeta: one global atomic per column per workgroup (partials of all its tiles)
+    lds_barrier();
+    for (int n = tid; n < p.ln_C; n += 512) {
+      atomicAdd(p.ln_dgamma + n, colred[n]);
+      atomicAdd(p.ln_dbeta + n, colred[SBN + n]);
+    }
+  }
+}
+
+int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
+int g_num_cus = 0;
+
+template <int EP, int KC, int BM, bool KS2>
+int launch_stream(const GemmParams& p, hipStream_t stream) {
+  using C = StreamCfg<EP, KC, BM>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<EP, KC, BM, KS2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
+      srk_set_error("gemm(stream): cannot reserve %d bytes of LDS", C::LDS);
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  const int nchunk = p.N / SBN;
+  const int per_xcd = g_num_cus / 8;
+  const int groups_per_xcd = per_xcd / nchunk;
+  srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
+  hipLaunchKernelGGL((gemm_stream_kernel<EP, KC, BM, KS2>), dim3(per_xcd * 8), dim3(512), C::LDS, stream, p, nchunk, groups_per_xcd);
+  srk_probe_post(FAM_GEMM_LINEAR, stream);
+  return srk_check_launch("gemm(stream)");
+}
+
+template <int EP, int BM192, int BM384, bool KS2_384>
+int dispatch_k(const GemmParams& p, hipStream_t stream) {
+  if (p.K == 192) return launch_stream<EP, 3, BM192, false>(p, stream);
+  if (p.K == 384) return launch_stream<EP, 6, BM384, KS2_384>(p, stream);
+  return SRK_NOT_COVERED;
+}
+
+}  // namespace
+
+// 1: use the streaming kernel where it applies (default); 0: always use the tile kernel of gemm.hip
+void srk_gemm_stream_enable(int on) { g_stream_enabled = on ? 1 : 0; }
+
+// Returns SRK_NOT_COVERED when the streaming kernel does not cover this problem (the caller then uses the tile kernel).
+int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream) {
+  if (g_stream_enabled < 0) {
+    const char* e = getenv("SRK_GEMM_STREAM");
+    g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_stream_enabled) return SRK_NOT_COVERED;
+  if (g_num_cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    g_num_cus = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount & ~7;
+  }
+  if (g_num_cus < 8) return SRK_NOT_COVERED;
+  if (p.N % SBN != 0 || p.M % 64 != 0 || p.lda % 8 != 0 || p.N / SBN > g_num_cus / 8) return SRK_NOT_COVERED;
+  if (p.M < 64 * g_num_cus) return SRK_NOT_COVERED;            // too few tiles to fill the persistent grid
+  switch (epilogue) {
+    case EP_BF16: return dispatch_k<EP_BF16, 64, 32, false>(p, stream);
+    case EP_QKV: return dispatch_k<EP_QKV, 64, 32, false>(p, stream);
+    case EP_GELU: return dispatch_k<EP_GELU, 64, 32, false>(p, stream);
+    case EP_DGELU: return dispatch_k<EP_DGELU, 32, 32, false>(p, stream);
+    case EP_PROJ_RES: if (p.N != SBN) return SRK_NOT_COVERED; return dispatch_k<EP_PROJ_RES, 32, 16, false>(p, stream);
+    case EP_RES: if (p.N != SBN) return SRK_NOT_COVERED; return dispatch_k<EP_RES, 32, 16, false>(p, stream);
+    case EP_LNBWD:
+      if (p.N != SBN) return SRK_NOT_COVERED;
+      if (p.K == 576) return launch_stream<EP_LNBWD, 9, 16, true>(p, stream);
+      return dispatch_k<EP_LNBWD, 16, 16, true>(p, stream);
+    default: return SRK_NOT_COVERED;
+  }
+}
