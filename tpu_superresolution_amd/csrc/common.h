@@ -147,11 +147,20 @@ __device__ __forceinline__ const bf16_t* tr_addr(const bf16_t* tile, int stride,
   return tile + (rbase + (ll >> 2)) * stride + c0 + ((ll & 3) << 2);
 }
 
-__device__ __forceinline__ float wave_sum16(float v) {  // reduce across the 16 lanes sharing lane>>4
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+// value of another lane of the same 16-lane DPP row (cross-lane VALU operand, no LDS round trip):
+// 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x141 row_half_mirror (i <-> 7-i), 0x140 row_mirror (i <-> 15-i)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 16 lanes sharing lane>>4, result in all of them (bitwise identical: every lane adds the same pairs).
+// Same pairing tree as an xor-1/2/4/8 butterfly, but 4 DPP adds instead of 4 dependent ds_bpermute round trips.
+__device__ __forceinline__ float wave_sum16(float v) {
+  v += dpp_row<0xB1>(v);
+  v += dpp_row<0x4E>(v);
+  v += dpp_row<0x141>(v);
+  v += dpp_row<0x140>(v);
   return v;
 }
 

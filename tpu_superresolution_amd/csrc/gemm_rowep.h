@@ -12,8 +12,19 @@
 
 // LayerNorm (eps 1e-5) of a row held as NC float4 per lane by a 16-lane group -> bf16 row + stats
 template <int NC>
+__device__ __forceinline__ void fused_ln_row_at(const GemmParams& p, const float4 (&o)[NC], long long ro, int j16,
+                                                const float (&lg)[NC][4], const float (&lb)[NC][4]);
+
+template <int NC>
 __device__ __forceinline__ void fused_ln_row(const GemmParams& p, const float4 (&o)[NC], long long t, int j16,
                                              const float (&lg)[NC][4], const float (&lb)[NC][4]) {
+  fused_ln_row_at<NC>(p, o, p.xn_window ? token_to_win_row(p.xn_geom, (int)t) : t, j16, lg, lb);
+}
+
+// same, with the output row already resolved
+template <int NC>
+__device__ __forceinline__ void fused_ln_row_at(const GemmParams& p, const float4 (&o)[NC], long long ro, int j16,
+                                                const float (&lg)[NC][4], const float (&lb)[NC][4]) {
   const float invC = 1.0f / (float)p.xn_C;
   float s = 0.f;
 #pragma unroll
@@ -31,7 +42,6 @@ __device__ __forceinline__ void fused_ln_row(const GemmParams& p, const float4 (
     }
   }
   const float rstd = rsqrtf(wave_sum16(q) * invC + 1e-5f);
-  const long long ro = p.xn_window ? token_to_win_row(p.xn_geom, (int)t) : t;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     float y[4];

@@ -64,7 +64,7 @@ struct StreamCfg {
   static constexpr int A_BYTES = BM * K * 2;
   static constexpr int E32_BYTES = BM * SBN * 4;
   static constexpr int E16_BYTES = BM * SBN * 2;
-  static constexpr int AUX_BYTES = AUX ? 4 * 64 * 4 : 0;          // one 64-float array per loader wave
+  static constexpr int AUX_BYTES = AUX ? 6 * 64 * 4 : 0;          // 4 DMA'd float arrays (one per loader wave) + row maps tok / ro
   static constexpr int SLOT = A_BYTES + NE32 * E32_BYTES + NE16 * E16_BYTES + AUX_BYTES;
   static constexpr int T_BYTES = BM * SBNP * 4;
   static constexpr int RED_BYTES = (EP == EP_LNBWD) ? 2 * SBN * 4 : 0;
@@ -76,15 +76,16 @@ struct StreamCfg {
   static constexpr int R_LDS = (LDS_BUDGET - T_BYTES - RED_BYTES) / SLOT;
   static constexpr int R_CNT = 2 + 63 / P;                         // vmcnt is a 6-bit counter
   static constexpr int R0 = R_LDS < R_CNT ? R_LDS : R_CNT;
-  static constexpr int R = R0 > 8 ? 8 : R0;
+  static constexpr int R = R0 > 8 ? 8 : (R0 < 2 ? 2 : R0);
+  static constexpr bool VALID = R0 >= 2;                             // the ring needs at least one tile in flight
   static constexpr int LDS = T_BYTES + RED_BYTES + R * SLOT;
-  static_assert(R >= 2, "streaming GEMM: ring too shallow for this tile");
   static_assert(P * (R - 2) <= 63, "vmcnt overflow");
 };
 
 // ---- loader: all DMAs of one tile ------------------------------------------------------------
 template <int EP, int KC, int BM>
-__device__ __forceinline__ void stream_issue_tile(const GemmParams& p, int m0, int n0, unsigned slot, int lw, int lane) {
+__device__ __forceinline__ void stream_issue_tile(const GemmParams& p, int m0, int n0, unsigned slot, int lw, int lane, unsigned char* smem_ptr,
+                                                  unsigned smem_base) {
   using C = StreamCfg<EP, KC, BM>;
   constexpr int CRA = C::K / 8;
 #pragma unroll
@@ -148,6 +149,189 @@ __device__ __forceinline__ void stream_issue_tile(const GemmParams& p, int m0, i
         if (lw == 0 && p.rowscale) src = p.rowscale + t / p.rows_per_sample;
       }
       glds4(src, __builtin_amdgcn_readfirstlane(off + lw * 256));
+      // row maps of the tile (consumers would otherwise redo these integer divisions per row-quad): tok = raster token of
+      // tile row `lane`, ro = row of the bf16 side output (fused LayerNorm output / windowed gradient copy)
+      if (lw == 3) {
+        int ro = (int)t;
+        if constexpr (EP == EP_LNBWD) {
+          if (p.ln_out_window) ro = token_to_win_row(p.geom, (int)t);
+        } else {
+          if (p.xn_out && p.xn_window) ro = token_to_win_row(p.xn_geom, (int)t);
+        }
+        int* maps = reinterpret_cast<int*>(smem_ptr + (off - smem_base) + 4 * 256);
+        maps[lane] = (int)t;
+        maps[64 + lane] = ro;
+      }
+    }
+  }
+}
+
+// ---- per-lane state of the row-major epilogue (lane j16 of a 16-lane group owns columns 64c + 4 j16 .. +3) ----------
+struct EpState {
+  float4 bias[NC];
+  float gm[NC][4], cg[NC][4], cb[NC][4];   // EP_LNBWD: gamma, dgamma / dbeta partials
+  float lg[NC][4], lb[NC][4];              // fused forward LayerNorm: gamma / beta
+  float invC;
+  bool has_scale;
+};
+
+#define EP_STATE_REFS(st)                       \
+  float4(&bias)[NC] = st.bias;                  \
+  float(&gm)[NC][4] = st.gm;                    \
+  float(&cg)[NC][4] = st.cg;                    \
+  float(&cb)[NC][4] = st.cb;                    \
+  float(&lg)[NC][4] = st.lg;                    \
+  float(&lb)[NC][4] = st.lb;                    \
+  float& invC = st.invC;                        \
+  bool& has_scale = st.has_scale;               \
+  (void)bias; (void)gm; (void)cg; (void)cb; (void)lg; (void)lb; (void)invC; (void)has_scale
+
+template <int EP>
+__device__ __forceinline__ void ep_init(const GemmParams& p, int n0, int j16, EpState& st) {
+  EP_STATE_REFS(st);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    bias[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EP != EP_DGELU && EP != EP_LNBWD) {
+      if (p.bias) bias[c] = *reinterpret_cast<const float4*>(p.bias + n0 + 64 * c + 4 * j16);
+    }
+  }
+  if constexpr (EP == EP_LNBWD) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 64 * c + 4 * j16 + e;
+        gm[c][e] = n < p.ln_C ? p.ln_gamma[n] : 0.f;
+        cg[c][e] = 0.f;
+        cb[c][e] = 0.f;
+      }
+  }
+  invC = EP == EP_LNBWD ? 1.0f / (float)p.ln_C : 0.f;
+  if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
+    if (p.xn_out) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 64 * c + 4 * j16 + e;
+          lg[c][e] = n < p.xn_C ? p.xn_gamma[n] : 0.f;
+          lb[c][e] = n < p.xn_C ? p.xn_beta[n] : 0.f;
+        }
+    }
+  }
+  has_scale = p.rowscale != nullptr;
+}
+
+// row-major epilogue of one tile: T = accumulators [BM][SBNP], slot = the tile's LDS slot (A image, row operands, row
+// scalars, row maps); the calling wave (0..3) handles rows 16 ps + 4 wave + (lane >> 4)
+template <int EP, int KC, int BM>
+__device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const float* T, const unsigned char* slot, int m0, int n0,
+                                                     int wave, int lane, EpState& st) {
+  using C = StreamCfg<EP, KC, BM>;
+  constexpr int MF = BM / 16;
+  EP_STATE_REFS(st);
+  const int sub = lane >> 4, j16 = lane & 15;
+  // ---- row-major epilogue: 16 lanes per row, lane j16 holds columns 64c + 4 j16 .. +3 -----------------
+  const unsigned char* e0 = slot + C::A_BYTES;
+  const float* auxf = reinterpret_cast<const float*>(slot + C::A_BYTES + C::NE32 * C::E32_BYTES + C::NE16 * C::E16_BYTES);
+  const int* maps = reinterpret_cast<const int*>(auxf + 4 * 64);
+#pragma unroll
+  for (int ps = 0; ps < MF; ++ps) {
+    const int lr = ps * 16 + wave * 4 + sub;
+    const int m = m0 + lr;
+    float4 v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      v[c] = *reinterpret_cast<const float4*>(T + lr * SBNP + 64 * c + 4 * j16);
+      v[c].x += bias[c].x; v[c].y += bias[c].y; v[c].z += bias[c].z; v[c].w += bias[c].w;
+    }
+    if constexpr (EP == EP_BF16) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+    } else if constexpr (EP == EP_QKV) {
+      const long long b_ = m >> 6;
+      const int tok = m & 63;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int n = n0 + 64 * c + 4 * j16;
+        const int which = n / p.CA, rem = n - which * p.CA;
+        const int h = rem >> 5, d = rem & 31;
+        const float s = which == 0 ? p.scale : 1.0f;
+        bf16_t* dst = p.outb + ((((long long)which * p.B_ + b_) * p.nH + h) * 64 + tok) * 32 + d;
+        *reinterpret_cast<uint2*>(dst) = pack_bf4(v[c].x * s, v[c].y * s, v[c].z * s, v[c].w * s);
+      }
+    } else if constexpr (EP == EP_GELU) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const long long o = (long long)m * p.ldo + n0 + 64 * c + 4 * j16;
+        *reinterpret_cast<uint2*>(p.outb + o) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+        *reinterpret_cast<uint2*>(p.outb2 + o) = pack_bf4(gelu_f(v[c].x), gelu_f(v[c].y), gelu_f(v[c].z), gelu_f(v[c].w));
+      }
+    } else if constexpr (EP == EP_DGELU) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const uint2 ua = *reinterpret_cast<const uint2*>(e0 + lr * (SBN * 2) + (64 * c + 4 * j16) * 2);
+        float u0, u1, u2, u3;
+        unpack_bf2(ua.x, u0, u1);
+        unpack_bf2(ua.y, u2, u3);
+        *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) =
+            pack_bf4(v[c].x * dgelu_f(u0), v[c].y * dgelu_f(u1), v[c].z * dgelu_f(u2), v[c].w * dgelu_f(u3));
+      }
+    } else if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
+      const long long t_ = maps[lr];
+      const float f = has_scale ? auxf[lr] : 1.0f;
+      float4 o[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float4 rv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+        o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
+        *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + n0 + 64 * c + 4 * j16) = o[c];
+        if constexpr (EP == EP_RES) {
+          if (p.outb) *reinterpret_cast<uint2*>(p.outb + t_ * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w);
+        }
+      }
+      if (p.xn_out) fused_ln_row_at<NC>(p, o, maps[64 + lr], j16, lg, lb);
+    } else if constexpr (EP == EP_LNBWD) {
+      const long long t_ = maps[lr];
+      const float mean = auxf[lr], rstd = auxf[64 + lr];
+      const float f = has_scale ? auxf[128 + lr] : 1.0f;
+      float xh[NC][4], dy[NC][4];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float4 xv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float dv[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dy[c][e] = dv[e];
+          xh[c][e] = 64 * c + 4 * j16 + e < p.ln_C ? (xs[e] - mean) * rstd : 0.f;
+          const float dg = dv[e] * gm[c][e];
+          s1 += dg;
+          s2 += dg * xh[c][e];
+        }
+      }
+      s1 = wave_sum16(s1) * invC;
+      s2 = wave_sum16(s2) * invC;
+      const long long ro = maps[64 + lr];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float4 old = *reinterpret_cast<const float4*>(e0 + C::E32_BYTES + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+        float o[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (64 * c + 4 * j16 + e < p.ln_C) {
+            o[e] += rstd * (dy[c][e] * gm[c][e] - s1 - xh[c][e] * s2);
+            cg[c][e] += dy[c][e] * xh[c][e];
+            cb[c][e] += dy[c][e];
+          }
+        }
+        *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + 64 * c + 4 * j16) = make_float4(o[0], o[1], o[2], o[3]);
+        if (p.outb)
+          *reinterpret_cast<uint2*>(p.outb + ro * p.ldo + 64 * c + 4 * j16) = pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f);
+      }
     }
   }
 }
@@ -205,13 +389,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, in
     // =================================== loader waves =============================================
     const int lw = wave - 4;
     for (int s = 0; s < R - 1 && s < nt; ++s)
-      stream_issue_tile<EP, KC, BM>(p, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane);
+      stream_issue_tile<EP, KC, BM>(p, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
     for (int t = 0; t < nt; ++t) {
       // tile t has landed once at most the (R-2) tiles issued after it are outstanding
       if (t + R - 2 < nt) wait_vmcnt<C::P*(R - 2)>(); else wait_vmcnt<0>();
       lds_barrier();                                                                 // B1
       if (t + R - 1 < nt)
-        stream_issue_tile<EP, KC, BM>(p, (gi + (t + R - 1) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((t + R - 1) % R) * C::SLOT, lw, lane);
+        stream_issue_tile<EP, KC, BM>(p, (gi + (t + R - 1) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((t + R - 1) % R) * C::SLOT, lw, lane, smem, smem_base);
       if constexpr (KS2) {
         const unsigned char* As = smem + SLOTS_OFF + (t % R) * C::SLOT;
         f32x4_t acc[MF][3];
@@ -243,42 +427,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, in
     }
   } else {
     // =================================== consumer waves ===========================================
-    const int sub = g, j16 = r16;
-    float4 bias[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      bias[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (EP != EP_DGELU && EP != EP_LNBWD) {
-        if (p.bias) bias[c] = *reinterpret_cast<const float4*>(p.bias + n0 + 64 * c + 4 * j16);
-      }
-    }
-    float gm[NC][4], cg[NC][4], cb[NC][4];
-    if constexpr (EP == EP_LNBWD) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = 64 * c + 4 * j16 + e;
-          gm[c][e] = n < p.ln_C ? p.ln_gamma[n] : 0.f;
-          cg[c][e] = 0.f;
-          cb[c][e] = 0.f;
-        }
-    }
-    const float invC = EP == EP_LNBWD ? 1.0f / (float)p.ln_C : 0.f;
-    float lg[NC][4], lb[NC][4];
-    if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
-      if (p.xn_out) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = 64 * c + 4 * j16 + e;
-            lg[c][e] = n < p.xn_C ? p.xn_gamma[n] : 0.f;
-            lb[c][e] = n < p.xn_C ? p.xn_beta[n] : 0.f;
-          }
-      }
-    }
-    const bool has_scale = p.rowscale != nullptr;
+    EpState st;
+    ep_init<EP>(p, n0, r16, st);
 
     for (int t = 0; t < nt; ++t) {
       const int m0 = (gi + t * Gm) * BM;
@@ -309,116 +459,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, in
       if constexpr (KS2) lds_barrier();                                              // Bm
       lds_barrier();                                                                 // B2: T is complete
 
-      // ---- row-major epilogue: 16 lanes per row, lane j16 holds columns 64c + 4 j16 .. +3 -----------------
-      const unsigned char* e0 = slot + C::A_BYTES;
-      const float* auxf = reinterpret_cast<const float*>(slot + C::A_BYTES + C::NE32 * C::E32_BYTES + C::NE16 * C::E16_BYTES);
-#pragma unroll
-      for (int ps = 0; ps < MF; ++ps) {
-        const int lr = ps * 16 + wave * 4 + sub;
-        const int m = m0 + lr;
-        float4 v[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          v[c] = *reinterpret_cast<const float4*>(T + lr * SBNP + 64 * c + 4 * j16);
-          v[c].x += bias[c].x; v[c].y += bias[c].y; v[c].z += bias[c].z; v[c].w += bias[c].w;
-        }
-        if constexpr (EP == EP_BF16) {
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-            *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
-        } else if constexpr (EP == EP_QKV) {
-          const long long b_ = m >> 6;
-          const int tok = m & 63;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int n = n0 + 64 * c + 4 * j16;
-            const int which = n / p.CA, rem = n - which * p.CA;
-            const int h = rem >> 5, d = rem & 31;
-            const float s = which == 0 ? p.scale : 1.0f;
-            bf16_t* dst = p.outb + ((((long long)which * p.B_ + b_) * p.nH + h) * 64 + tok) * 32 + d;
-            *reinterpret_cast<uint2*>(dst) = pack_bf4(v[c].x * s, v[c].y * s, v[c].z * s, v[c].w * s);
-          }
-        } else if constexpr (EP == EP_GELU) {
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const long long o = (long long)m * p.ldo + n0 + 64 * c + 4 * j16;
-            *reinterpret_cast<uint2*>(p.outb + o) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
-            *reinterpret_cast<uint2*>(p.outb2 + o) = pack_bf4(gelu_f(v[c].x), gelu_f(v[c].y), gelu_f(v[c].z), gelu_f(v[c].w));
-          }
-        } else if constexpr (EP == EP_DGELU) {
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const uint2 ua = *reinterpret_cast<const uint2*>(e0 + lr * (SBN * 2) + (64 * c + 4 * j16) * 2);
-            float u0, u1, u2, u3;
-            unpack_bf2(ua.x, u0, u1);
-            unpack_bf2(ua.y, u2, u3);
-            *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) =
-                pack_bf4(v[c].x * dgelu_f(u0), v[c].y * dgelu_f(u1), v[c].z * dgelu_f(u2), v[c].w * dgelu_f(u3));
-          }
-        } else if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
-          long long t_ = m;
-          if constexpr (EP == EP_PROJ_RES) t_ = win_row_to_token(p.geom, m);
-          const float f = has_scale ? auxf[lr] : 1.0f;
-          float4 o[NC];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const float4 rv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
-            o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
-            *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + n0 + 64 * c + 4 * j16) = o[c];
-            if constexpr (EP == EP_RES) {
-              if (p.outb) *reinterpret_cast<uint2*>(p.outb + t_ * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w);
-            }
-          }
-          if (p.xn_out) fused_ln_row<NC>(p, o, t_, j16, lg, lb);
-        } else if constexpr (EP == EP_LNBWD) {
-          const long long t_ = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
-          const float mean = auxf[lr], rstd = auxf[64 + lr];
-          const float f = has_scale ? auxf[128 + lr] : 1.0f;
-          float xh[NC][4], dy[NC][4];
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const float4 xv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            const float dv[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              dy[c][e] = dv[e];
-              xh[c][e] = 64 * c + 4 * j16 + e < p.ln_C ? (xs[e] - mean) * rstd : 0.f;
-              const float dg = dv[e] * gm[c][e];
-              s1 += dg;
-              s2 += dg * xh[c][e];
-            }
-          }
-          s1 = wave_sum16(s1) * invC;
-          s2 = wave_sum16(s2) * invC;
-          const long long ro = p.ln_out_window ? token_to_win_row(p.geom, (int)t_) : t_;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const float4 old = *reinterpret_cast<const float4*>(e0 + C::E32_BYTES + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
-            float o[4] = {old.x, old.y, old.z, old.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (64 * c + 4 * j16 + e < p.ln_C) {
-                o[e] += rstd * (dy[c][e] * gm[c][e] - s1 - xh[c][e] * s2);
-                cg[c][e] += dy[c][e] * xh[c][e];
-                cb[c][e] += dy[c][e];
-              }
-            }
-            *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + 64 * c + 4 * j16) = make_float4(o[0], o[1], o[2], o[3]);
-            if (p.outb)
-              *reinterpret_cast<uint2*>(p.outb + ro * p.ldo + 64 * c + 4 * j16) = pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f);
-          }
-        }
-      }
+      stream_epilogue_tile<EP, KC, BM>(p, T, slot, m0, n0, wave, lane, st);
     }
     if constexpr (EP == EP_LNBWD) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          atomicAdd(&colred[64 * c + 4 * j16 + e], cg[c][e]);
-          atomicAdd(&colred[SBN + 64 * c + 4 * j16 + e], cb[c][e]);
+          atomicAdd(&colred[64 * c + 4 * r16 + e], st.cg[c][e]);
+          atomicAdd(&colred[SBN + 64 * c + 4 * r16 + e], st.cb[c][e]);
         }
     }
   }
@@ -432,34 +481,231 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, in
   }
 }
 
+// ---- role-split variant: MFMA on the loader waves, epilogue on the consumer waves, ONE barrier per tile ---------------
+// Iteration i: the front waves (4-7: loaders, each also owns a 48-column slice of W in registers) run the MFMA of tile i
+// into T[i & 1] while the back waves (0-3) run the row epilogue of tile i-1 from T[(i-1) & 1]; the MFMA pipe and the
+// epilogue's VALU / LDS / store work then overlap on every SIMD instead of alternating.  A slot stays busy one iteration
+// longer (until its epilogue is done), so the ring keeps R-2 tiles in flight.
+template <int EP, int KC, int BM>
+struct SplitCfg {
+  using C = StreamCfg<EP, KC, BM>;
+  static constexpr int R_LDS = (LDS_BUDGET - 2 * C::T_BYTES - C::RED_BYTES) / C::SLOT;
+  static constexpr int R_CNT = 3 + 63 / C::P;
+  static constexpr int R0 = R_LDS < R_CNT ? R_LDS : R_CNT;
+  static constexpr int R = R0 > 8 ? 8 : (R0 < 3 ? 3 : R0);
+  static constexpr bool VALID = R0 >= 3 && KC <= 6;        // K = 576 would need 216 VGPRs of W per front wave
+  static constexpr int LDS = 2 * C::T_BYTES + C::RED_BYTES + R * C::SLOT;
+  static_assert(C::P * (R - 3) <= 63, "vmcnt overflow");
+};
+
+template <int EP, int KC, int BM>
+__global__ __launch_bounds__(512) void gemm_stream_split_kernel(const GemmParams p, int nchunk, int groups_per_xcd) {
+  using C = StreamCfg<EP, KC, BM>;
+  using S = SplitCfg<EP, KC, BM>;
+  constexpr int K = C::K, R = S::R, MF = BM / 16, KST = K / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* colred = reinterpret_cast<float*>(smem + 2 * C::T_BYTES);
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  constexpr int SLOTS_OFF = 2 * C::T_BYTES + C::RED_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, sx = blockIdx.x >> 3;
+  const int chunk = sx % nchunk, gx = sx / nchunk;
+  if (gx >= groups_per_xcd) return;
+  const int n0 = chunk * SBN;
+  const int Gm = 8 * groups_per_xcd, gi = gx * 8 + xcd;
+  const int ntm = p.M / BM;
+  const int nt = gi < ntm ? (ntm - gi + Gm - 1) / Gm : 0;
+  if (nt == 0) return;
+  if constexpr (EP == EP_LNBWD) {
+    for (int i = tid; i < 2 * SBN; i += 512) colred[i] = 0.f;
+  }
+
+  if (wave >= 4) {
+    // =================================== front waves: DMA + MFMA ===================================
+    const int lw = wave - 4, wn = lw;
+    bf16x8_t wf[3][KST];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < KST; ++s)
+        wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(n0 + wn * 48 + 16 * j + r16) * K + s * 32 + g * 8);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < KST; ++s) asm volatile("" ::"v"(wf[j][s]));     // retire the loads before the DMA ring starts
+
+    for (int s = 0; s < R - 2 && s < nt; ++s)
+      stream_issue_tile<EP, KC, BM>(p, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
+    for (int i = 0; i < nt; ++i) {
+      // this wave's DMAs of tile i have landed once at most the R-3 tiles issued after it are outstanding
+      if (i + R - 3 < nt) wait_vmcnt<C::P*(R - 3)>(); else wait_vmcnt<0>();
+      lds_barrier();                        // barrier(i): tile i complete in LDS; epilogue(i-2) done -> its slot and T are free
+      if (i + R - 2 < nt)
+        stream_issue_tile<EP, KC, BM>(p, (gi + (i + R - 2) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((i + R - 2) % R) * C::SLOT, lw, lane, smem,
+                                      smem_base);
+      const unsigned char* slot = smem + SLOTS_OFF + (i % R) * C::SLOT;
+      float* T = reinterpret_cast<float*>(smem + (i & 1) * C::T_BYTES);
+      f32x4_t acc[MF][3];
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[a][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KST; ++s)
+#pragma unroll
+        for (int a = 0; a < MF; ++a) {
+          const int row = 16 * a + r16;
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(slot + row * (K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[a][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          *reinterpret_cast<float4*>(T + (16 * a + r16) * SBNP + wn * 48 + 16 * j + 4 * g) =
+              make_float4(acc[a][j][0], acc[a][j][1], acc[a][j][2], acc[a][j][3]);
+    }
+    lds_barrier();                          // barrier(nt)
+  } else {
+    // =================================== back waves: row epilogue ==================================
+    EpState st;
+    ep_init<EP>(p, n0, r16, st);
+    for (int i = 0; i <= nt; ++i) {
+      lds_barrier();                        // barrier(i): T[(i-1) & 1] holds tile i-1
+      if (i > 0) {
+        const int t = i - 1;
+        stream_epilogue_tile<EP, KC, BM>(p, reinterpret_cast<const float*>(smem + (t & 1) * C::T_BYTES),
+                                         smem + SLOTS_OFF + (t % R) * C::SLOT, (gi + t * Gm) * BM, n0, wave, lane, st);
+      }
+    }
+    if constexpr (EP == EP_LNBWD) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(&colred[64 * c + 4 * r16 + e], st.cg[c][e]);
+          atomicAdd(&colred[SBN + 64 * c + 4 * r16 + e], st.cb[c][e]);
+        }
+    }
+  }
+  if constexpr (EP == EP_LNBWD) {
+    lds_barrier();
+    for (int n = tid; n < p.ln_C; n += 512) {
+      atomicAdd(p.ln_dgamma + n, colred[n]);
+      atomicAdd(p.ln_dbeta + n, colred[SBN + n]);
+    }
+  }
+}
+
 int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
 int g_num_cus = 0;
+int g_tune_bm = 0;             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
+int g_tune_ks2 = -1;           // split K over the two wave groups: 0/1, -1 = default
+int g_tune_split = -1;         // role-split kernel (MFMA on the loader waves): 0/1, -1 = default
+
+template <typename KernelT>
+int stream_configure(KernelT kernel, int lds, int* state) {
+  if (*state) return SRK_OK;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, fn) != hipSuccess) {
+    srk_set_error("gemm(stream): cannot query the kernel");
+    return SRK_E_LAUNCH;
+  }
+  // a variant that spills would put scratch traffic on the loaders' vmcnt counter: never run it
+  if (attr.localSizeBytes > 0) {
+    *state = -1;
+    return SRK_OK;
+  }
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    srk_set_error("gemm(stream): cannot reserve %d bytes of LDS", lds);
+    return SRK_E_LAUNCH;
+  }
+  *state = 1;
+  return SRK_OK;
+}
+
+template <int EP, int KC, int BM>
+int launch_split(const GemmParams& p, hipStream_t stream) {
+  using S = SplitCfg<EP, KC, BM>;
+  if constexpr (!S::VALID) {
+    return SRK_NOT_COVERED;
+  } else {
+    static int configured = 0;     // 1 usable, -1 not usable
+    const int rc = stream_configure(&gemm_stream_split_kernel<EP, KC, BM>, S::LDS, &configured);
+    if (rc) return rc;
+    if (configured < 0) return SRK_NOT_COVERED;
+    const int nchunk = p.N / SBN;
+    const int per_xcd = g_num_cus / 8;
+    srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
+    hipLaunchKernelGGL((gemm_stream_split_kernel<EP, KC, BM>), dim3(per_xcd * 8), dim3(512), S::LDS, stream, p, nchunk, per_xcd / nchunk);
+    srk_probe_post(FAM_GEMM_LINEAR, stream);
+    return srk_check_launch("gemm(stream-split)");
+  }
+}
 
 template <int EP, int KC, int BM, bool KS2>
 int launch_stream(const GemmParams& p, hipStream_t stream) {
   using C = StreamCfg<EP, KC, BM>;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<EP, KC, BM, KS2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
-      srk_set_error("gemm(stream): cannot reserve %d bytes of LDS", C::LDS);
-      return SRK_E_LAUNCH;
-    }
-    configured = true;
+  if constexpr (!C::VALID || (KC == 9 && !KS2)) {
+    return SRK_NOT_COVERED;
+  } else {
+    static int configured = 0;     // 1 usable, -1 not usable
+    const int rcc = stream_configure(&gemm_stream_kernel<EP, KC, BM, KS2>, C::LDS, &configured);
+    if (rcc) return rcc;
+    if (configured < 0) return SRK_NOT_COVERED;
+    const int nchunk = p.N / SBN;
+    const int per_xcd = g_num_cus / 8;
+    const int groups_per_xcd = per_xcd / nchunk;
+    srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
+    hipLaunchKernelGGL((gemm_stream_kernel<EP, KC, BM, KS2>), dim3(per_xcd * 8), dim3(512), C::LDS, stream, p, nchunk, groups_per_xcd);
+    srk_probe_post(FAM_GEMM_LINEAR, stream);
+    return srk_check_launch("gemm(stream)");
   }
-  const int nchunk = p.N / SBN;
-  const int per_xcd = g_num_cus / 8;
-  const int groups_per_xcd = per_xcd / nchunk;
-  srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
-  hipLaunchKernelGGL((gemm_stream_kernel<EP, KC, BM, KS2>), dim3(per_xcd * 8), dim3(512), C::LDS, stream, p, nchunk, groups_per_xcd);
-  srk_probe_post(FAM_GEMM_LINEAR, stream);
-  return srk_check_launch("gemm(stream)");
 }
 
-template <int EP, int BM192, int BM384, bool KS2_384>
-int dispatch_k(const GemmParams& p, hipStream_t stream) {
-  if (p.K == 192) return launch_stream<EP, 3, BM192, false>(p, stream);
-  if (p.K == 384) return launch_stream<EP, 6, BM384, KS2_384>(p, stream);
+template <int EP, int KC>
+int launch_cfg(const GemmParams& p, hipStream_t stream, int bm, bool ks2) {
+  if (bm == 16) return ks2 ? launch_stream<EP, KC, 16, true>(p, stream) : launch_stream<EP, KC, 16, false>(p, stream);
+  if (bm == 32) return ks2 ? launch_stream<EP, KC, 32, true>(p, stream) : launch_stream<EP, KC, 32, false>(p, stream);
+  if (bm == 64) return ks2 ? launch_stream<EP, KC, 64, true>(p, stream) : launch_stream<EP, KC, 64, false>(p, stream);
+  return SRK_NOT_COVERED;
+}
+
+template <int EP, int KC>
+int launch_split_bm(const GemmParams& p, hipStream_t stream, int bm) {
+  if (bm == 16) return launch_split<EP, KC, 16>(p, stream);
+  if (bm == 32) return launch_split<EP, KC, 32>(p, stream);
+  if (bm == 64) return launch_split<EP, KC, 64>(p, stream);
+  return SRK_NOT_COVERED;
+}
+
+// per-(epilogue, K) defaults measured on MI355X (tools/stream_sweep.py); the overrides fall back to them
+struct StreamChoice {
+  int bm;        // rows per tile
+  bool ks2;      // symmetric kernel: split K over the two wave groups
+  bool split;    // role-split kernel
+};
+
+template <int EP, int KC>
+int pick(const GemmParams& p, hipStream_t stream, StreamChoice def) {
+  StreamChoice c = def;
+  if (g_tune_bm) c.bm = g_tune_bm;
+  if (g_tune_ks2 >= 0) c.ks2 = g_tune_ks2 != 0;
+  if (g_tune_split >= 0) c.split = g_tune_split != 0;
+  int rc = c.split ? launch_split_bm<EP, KC>(p, stream, c.bm) : launch_cfg<EP, KC>(p, stream, c.bm, c.ks2);
+  if (rc == SRK_NOT_COVERED) rc = def.split ? launch_split_bm<EP, KC>(p, stream, def.bm) : launch_cfg<EP, KC>(p, stream, def.bm, def.ks2);
+  return rc;
+}
+
+template <int EP>
+int dispatch_k(const GemmParams& p, hipStream_t stream, StreamChoice k192, StreamChoice k384) {
+  if (p.K == 192) return pick<EP, 3>(p, stream, k192);
+  if (p.K == 384) return pick<EP, 6>(p, stream, k384);
   return SRK_NOT_COVERED;
 }
 
@@ -467,6 +713,11 @@ int dispatch_k(const GemmParams& p, hipStream_t stream) {
 
 // 1: use the streaming kernel where it applies (default); 0: always use the tile kernel of gemm.hip
 void srk_gemm_stream_enable(int on) { g_stream_enabled = on ? 1 : 0; }
+void srk_gemm_stream_tune(int bm, int ks2, int split) {
+  g_tune_bm = bm;
+  g_tune_ks2 = ks2;
+  g_tune_split = split;
+}
 
 // Returns SRK_NOT_COVERED when the streaming kernel does not cover this problem (the caller then uses the tile kernel).
 int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream) {
@@ -485,16 +736,16 @@ int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream
   if (p.N % SBN != 0 || p.M % 64 != 0 || p.lda % 8 != 0 || p.N / SBN > g_num_cus / 8) return SRK_NOT_COVERED;
   if (p.M < 64 * g_num_cus) return SRK_NOT_COVERED;            // too few tiles to fill the persistent grid
   switch (epilogue) {
-    case EP_BF16: return dispatch_k<EP_BF16, 64, 32, false>(p, stream);
-    case EP_QKV: return dispatch_k<EP_QKV, 64, 32, false>(p, stream);
-    case EP_GELU: return dispatch_k<EP_GELU, 64, 32, false>(p, stream);
-    case EP_DGELU: return dispatch_k<EP_DGELU, 32, 32, false>(p, stream);
-    case EP_PROJ_RES: if (p.N != SBN) return SRK_NOT_COVERED; return dispatch_k<EP_PROJ_RES, 32, 16, false>(p, stream);
-    case EP_RES: if (p.N != SBN) return SRK_NOT_COVERED; return dispatch_k<EP_RES, 32, 16, false>(p, stream);
+    case EP_BF16: return dispatch_k<EP_BF16>(p, stream, {32, false, true}, {32, false, true});
+    case EP_QKV: return dispatch_k<EP_QKV>(p, stream, {64, false, false}, {32, false, true});   // front-bound when split: 3 slices share A
+    case EP_GELU: return dispatch_k<EP_GELU>(p, stream, {32, false, true}, {32, false, true});
+    case EP_DGELU: return dispatch_k<EP_DGELU>(p, stream, {32, false, true}, {32, false, true});
+    case EP_PROJ_RES: if (p.N != SBN) return SRK_NOT_COVERED; return dispatch_k<EP_PROJ_RES>(p, stream, {16, false, true}, {16, false, true});
+    case EP_RES: if (p.N != SBN) return SRK_NOT_COVERED; return dispatch_k<EP_RES>(p, stream, {16, false, true}, {16, false, true});
     case EP_LNBWD:
       if (p.N != SBN) return SRK_NOT_COVERED;
-      if (p.K == 576) return launch_stream<EP_LNBWD, 9, 16, true>(p, stream);
-      return dispatch_k<EP_LNBWD, 16, 16, true>(p, stream);
+      if (p.K == 576) return pick<EP_LNBWD, 9>(p, stream, {16, true, false});
+      return dispatch_k<EP_LNBWD>(p, stream, {16, true, false}, {16, true, false});
     default: return SRK_NOT_COVERED;
   }
 }
