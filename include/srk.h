@@ -100,6 +100,9 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
 /* Kernel-selection switches (A/B testing; results are equivalent up to fp32 summation order).
  *   "gemm_stream" 1 (default) / 0: use the persistent LDS-DMA GEMM (csrc/gemm_stream.hip) for the block GEMMs it
  *   covers, or always the tile-per-workgroup GEMM (csrc/gemm.hip).  Env SRK_GEMM_STREAM=0 sets the initial value.
+ *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1: tile-shape overrides of that
+ *   kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
+ *   "conv_wgrad_taps" 1 (default) / 0: all-taps conv weight gradient (csrc/convwgrad.hip) or the per-tap tiles.
  * Unknown names return SRK_E_UNSUPPORTED. */
 int srk_set_option(const char* name, int value);
 

@@ -157,7 +157,8 @@ def test_conv3x3(ops, B, H, W, Cin, CinP, Cout, NP):
     assert (y.cpu()[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("B,H,W,CinP,N", [(2, 16, 16, 64, 64), (1, 24, 16, 192, 192), (2, 8, 8, 64, 256)])
+@pytest.mark.parametrize("B,H,W,CinP,N", [(2, 16, 16, 64, 64), (1, 24, 16, 192, 192), (2, 8, 8, 64, 256),
+                                          (2, 8, 64, 64, 128), (1, 5, 128, 192, 192), (3, 3, 64, 128, 64)])   # W % 64 == 0: all-taps kernel
 def test_conv3x3_wgrad(ops, B, H, W, CinP, N):
     torch.manual_seed(5)
     x, dy = bf(torch.randn(B, H, W, CinP)), bf(torch.randn(B, H, W, N) * 0.1)

@@ -95,3 +95,26 @@ def test_stream_and_tile_paths_agree_on_a_cfg3_width_model(drop):
     print(f"drop={drop}: out diff {float((out1 - out0).abs().max()):.3e}, grad rel-L2 median {np.median(list(rels.values())):.3e}, worst {rels[worst]:.3e} ({worst})")
     assert rels[worst] <= 2e-2, f"{worst}: {rels[worst]:.3e}"
     assert float(np.median(list(rels.values()))) <= 4e-3
+
+
+def test_all_taps_conv_wgrad_matches_per_tap_tiles_on_the_model():
+    """csrc/convwgrad.hip (incl. the pixel-shuffled dY of the upsample conv) against the per-tap tiles of wgrad.hip."""
+    from tpu_superresolution_amd._lib import check, lib
+    cfg = _mid_cfg()
+    sd = O.random_state_dict(cfg, seed=9, scale=1.0)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand(4, 3, 64, 64, generator=gen).cuda()
+    t = torch.rand(4, 3, 128, 128, generator=gen).cuda()
+    res = {}
+    for on in (1, 0):
+        check(lib().srk_set_option(b"conv_wgrad_taps", on))
+        m = build(cfg, sd, train=True)
+        torch.nn.functional.l1_loss(m(x), t).backward()
+        torch.cuda.synchronize()
+        res[on] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+    check(lib().srk_set_option(b"conv_wgrad_taps", 1))
+    convs = [n for n in res[0] if (".conv." in n or n.startswith(("conv_", "upsample."))) and n != "conv_first.weight"]
+    assert len(convs) >= 8
+    for n in convs:
+        rel = float((res[1][n] - res[0][n]).norm() / (res[0][n].norm() + 1e-12))
+        assert rel <= 1e-4, f"{n}: {rel:.3e}"

@@ -239,6 +239,10 @@ int srk_set_option(const char* name, int value) {
     srk_gemm_stream_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "conv_wgrad_taps") == 0) {
+    srk_conv_wgrad_taps_enable(value);
+    return SRK_OK;
+  }
   static int bm = 0, ks2 = -1, split = -1;
   if (strcmp(name, "gemm_stream_bm") == 0) {
     SRK_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, SRK_E_SHAPE, "gemm_stream_bm: 0/16/32/64");

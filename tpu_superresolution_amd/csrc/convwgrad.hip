@@ -1,0 +1,203 @@
+// All-taps weight gradient of a 3x3 / stride 1 / pad 1 conv on NHWC bf16 (gfx950, v_mfma_f32_16x16x32_bf16):
+//
+//   dW[n][tap][k] += sum_{b,y,x} Y[b][y][x][n] * X[b][y+dy][x+dx][k]      db[n] += sum Y[b][y][x][n]
+//
+// wgrad.hip treats the nine taps as nine independent GEMM tiles: every tap re-reads the whole Y tile and a
+// shifted copy of the same X rows, and a workgroup gets 16-32 MFMAs per 24 KB it stages -- the kernel is bound
+// by staging latency at a few percent of either roofline.  Here a workgroup owns 64 output channels x 64 input
+// channels for ALL nine taps: per 64-pixel run of an image row it stages the Y rows once (8 KB) and the X halo
+// (3 rows x 66 pixels, 25 KB) once, and issues 288 MFMAs on them (each wave: all four n-fragments x nine of
+// the 36 (tap, k-fragment) column groups; 144 accumulator registers).  Operands are m-major in memory, so the
+// fragments come from the transposing LDS read, with the same row padding as wgrad.hip.
+#include "wgrad.h"
+
+namespace {
+
+constexpr int CT = 64;                 // pixels per chunk: one run inside an image row (needs W % 64 == 0)
+constexpr int SP = 64 + 16;            // LDS row stride in elements: 32 B x odd -> conflict-free transposing reads
+constexpr int HALO = CT + 2;           // pixels per halo row
+constexpr int XROWS = 3 * HALO;
+constexpr int YPIECES = CT * 8 / 256;                 // 16-byte pieces per thread
+constexpr int XPIECES = (XROWS * 8 + 255) / 256;
+
+template <bool SHUF>
+__global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(const WgradParams p, int ntiles, int chunks_per) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ys = reinterpret_cast<bf16_t*>(smem);      // [2][CT][SP]
+  bf16_t* Xs = Ys + 2 * CT * SP;                     // [2][XROWS][SP]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  // 1-D grid, (m-split, tile) with the tiles of one m-split contiguous on one XCD: they re-read the same rows
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bsplit = logical / ntiles, btile = logical - bsplit * ntiles;
+  const int ntn = p.N / 64;
+  const int tn = btile % ntn, tk = btile / ntn;
+  const int n0 = tn * 64, k0 = tk * 64;
+  const int c_begin = bsplit * chunks_per;
+  const int c_end = min(p.M / CT, c_begin + chunks_per);
+  if (c_begin >= c_end) return;
+  const int hw = p.H * p.W;
+
+  uint4 ry[YPIECES], rx[XPIECES];
+  auto load_stage = [&](int ch) {
+    const int m0 = ch * CT;
+    const int b = m0 / hw, rem = m0 - b * hw;
+    const int y = rem / p.W, x0 = rem - y * p.W;
+#pragma unroll
+    for (int t = 0; t < YPIECES; ++t) {
+      const int pid = tid + 256 * t;
+      const int row = pid >> 3, c8 = pid & 7;
+      if constexpr (SHUF) {
+        // Y lives pixel-shuffled: channel n = (si*r + sj)*Cs + c of pixel (y, x) is stored at [r*y+si][r*x+sj][c]
+        const int nn = n0 + c8 * 8;
+        const int ij = nn / p.Cs, c = nn - ij * p.Cs;
+        const int si = ij / p.r, sj = ij - si * p.r;
+        ry[t] = *reinterpret_cast<const uint4*>(
+            p.Y + (((long long)(b * p.H * p.r + y * p.r + si)) * (p.W * p.r) + (x0 + row) * p.r + sj) * p.Cs + c);
+      } else {
+        ry[t] = *reinterpret_cast<const uint4*>(p.Y + (long long)(m0 + row) * p.ldy + n0 + c8 * 8);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < XPIECES; ++t) {
+      const int pid = tid + 256 * t;
+      const int hr = pid >> 3, c8 = pid & 7;
+      const int rr = hr / HALO, px = hr - rr * HALO;
+      const int yy = y + rr - 1, xx = x0 + px - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (hr < XROWS && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4*>(p.X + ((long long)(b * p.H + yy) * p.W + xx) * p.ldx + k0 + c8 * 8);
+      rx[t] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    bf16_t* ys = Ys + buf * CT * SP;
+    bf16_t* xs = Xs + buf * XROWS * SP;
+#pragma unroll
+    for (int t = 0; t < YPIECES; ++t) {
+      const int pid = tid + 256 * t;
+      *reinterpret_cast<uint4*>(ys + (pid >> 3) * SP + (pid & 7) * 8) = ry[t];
+    }
+#pragma unroll
+    for (int t = 0; t < XPIECES; ++t) {
+      const int pid = tid + 256 * t;
+      if (pid < XROWS * 8) *reinterpret_cast<uint4*>(xs + (pid >> 3) * SP + (pid & 7) * 8) = rx[t];
+    }
+  };
+
+  f32x4_t acc[4][9], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[i][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.db != nullptr && tk == 0 && wave == 0;
+  const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  // this wave's nine column groups: cg = 9 wave + q -> (tap = cg / 4, k-fragment = cg % 4)
+  int xbase[9], xcol[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int cg = 9 * wave + q;
+    const int tap = cg >> 2, kf = cg & 3;
+    xbase[q] = (tap / 3) * HALO + (tap % 3);      // halo row of pixel (x0 + 0) shifted by (dy, dx)
+    xcol[q] = 16 * kf;
+  }
+
+  load_stage(c_begin);
+  store_stage(0);
+  __syncthreads();
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int buf = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) load_stage(ch + 1);
+    const bf16_t* ys = Ys + buf * CT * SP;
+    const bf16_t* xs = Xs + buf * XROWS * SP;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // k order inside a fragment: jj < 4 -> pixel 32ks + 4g + jj, jj >= 4 -> pixel 32ks + 16 + 4g + jj - 4 (same for Y and X)
+      bf16x8_t yf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4_t lo = lds_tr_read(tr_addr(ys, SP, 32 * ks + 4 * g, 16 * i, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(ys, SP, 32 * ks + 16 + 4 * g, 16 * i, lane));
+        yf[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SP, xbase[q] + 32 * ks + 4 * g, xcol[q], lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SP, xbase[q] + 32 * ks + 16 + 4 * g, xcol[q], lane));
+        const bf16x8_t xf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf, acc[i][q], 0, 0, 0);
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < c_end) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // acc[i][q][e] = dW[n = n0 + 16i + 4g + e][tap][k = k0 + 16kf + r16]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + 16 * i + 4 * g;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int cg = 9 * wave + q;
+      const long long col = (long long)(cg >> 2) * p.K + k0 + 16 * (cg & 3) + r16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, acc[i][q][e]);
+    }
+    if (do_bias && r16 == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.db + n + e, accb[i][e]);
+    }
+  }
+}
+
+int g_taps_enabled = 1;
+
+template <bool SHUF>
+int launch_taps(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * (CT + XROWS) * SP * sizeof(bf16_t);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<SHUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      srk_set_error("conv wgrad: cannot reserve %zu bytes of LDS", lds);
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  const int tiles = (p.N / 64) * (p.K / 64);
+  const int nchunks = p.M / CT;
+  // one workgroup per CU (LDS-limited): ~256 workgroups; every m-split costs one pass of fp32 atomics over the tile
+  int splits = 256 / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > nchunks) splits = nchunks;
+  const int chunks_per = cdiv(nchunks, splits);
+  splits = cdiv(nchunks, chunks_per);
+  srk_probe_pre(FAM_WGRAD_CONV, stream, p.flops, p.bytes);
+  hipLaunchKernelGGL((conv_wgrad_taps_kernel<SHUF>), dim3(tiles * splits), dim3(256), lds, stream, p, tiles, chunks_per);
+  srk_probe_post(FAM_WGRAD_CONV, stream);
+  return srk_check_launch("conv wgrad (all taps)");
+}
+
+}  // namespace
+
+void srk_conv_wgrad_taps_enable(int on) { g_taps_enabled = on ? 1 : 0; }
+
+// SRK_WGRAD_NOT_COVERED when the all-taps kernel does not apply (the caller then uses the per-tap tiles of wgrad.hip)
+int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream) {
+  if (!g_taps_enabled || !p.conv || p.W % CT != 0 || p.N % 64 != 0 || p.K % 64 != 0 || p.ldx % 8 != 0) return SRK_WGRAD_NOT_COVERED;
+  if (p.r > 1) {
+    if (p.Cs % 8 != 0 || p.N != p.r * p.r * p.Cs) return SRK_WGRAD_NOT_COVERED;
+    return launch_taps<true>(p, stream);
+  }
+  if (p.ldy % 8 != 0) return SRK_WGRAD_NOT_COVERED;
+  return launch_taps<false>(p, stream);
+}

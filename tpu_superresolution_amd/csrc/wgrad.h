@@ -27,4 +27,9 @@ struct WgradMulti {
 };
 
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);
+
+// convwgrad.hip: all-taps conv weight gradient (W % 64 == 0, N % 64 == 0, K % 64 == 0); SRK_WGRAD_NOT_COVERED otherwise
+#define SRK_WGRAD_NOT_COVERED 1
+int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream);
+void srk_conv_wgrad_taps_enable(int on);
 int srk_launch_wgrad_multi(const WgradParams* ps, int nprob, hipStream_t stream);

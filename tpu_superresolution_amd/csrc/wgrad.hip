@@ -250,6 +250,10 @@ int validate(const WgradParams& p) {
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
   int rc = validate(p);
   if (rc) return rc;
+  if (p.conv) {
+    rc = srk_launch_conv_wgrad_taps(p, stream);
+    if (rc != SRK_WGRAD_NOT_COVERED) return rc;
+  }
   return p.conv ? dispatch<true>(&p, 1, stream) : dispatch<false>(&p, 1, stream);
 }
 
