@@ -131,11 +131,12 @@ def main():
             gbs = by.value / (ms.value * 1e-3) / 1e9
             tfl = fl.value / (ms.value * 1e-3) / 1e12
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_pmc_linear_gemm_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "r01_pmc_linear_gemm_stream_traffic.json")
             if os.path.exists(tf):
                 traffic = json.load(open(tf))["avg_hbm_bytes_per_launch"]      # rocprofv3 PMC, same workload
-            roof = {"bound": "hbm", "kernel": "gemm_kernel<LD_ROWS,*> (linear layers: qkv/proj/fc1/fc2 forward and dgrad, with "
-                                               "their fused bias/GELU/residual/LayerNorm epilogues)",
+            roof = {"bound": "hbm", "kernel": "gemm_stream_kernel / gemm_stream_split_kernel (csrc/gemm_stream.hip: persistent LDS-DMA "
+                                               "GEMM of the linear layers -- qkv/proj/fc1/fc2 forward and dgrad with their fused "
+                                               "bias/GELU/residual/LayerNorm epilogues)",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value,
                     "avg_launch_us": 1e3 * ms.value / n.value, "share_of_step": ms.value / (1e3 * elapsed),

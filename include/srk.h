@@ -102,6 +102,8 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   covers, or always the tile-per-workgroup GEMM (csrc/gemm.hip).  Env SRK_GEMM_STREAM=0 sets the initial value.
  *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1: tile-shape overrides of that
  *   kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
+ *   "wgrad_stream" 1 (default) / 0: LDS-DMA ring variant of the 192x192 linear weight-gradient tile or the
+ *   register-staged one (both in csrc/wgrad.hip).
  *   "conv_wgrad_taps" 1 (default) / 0: all-taps conv weight gradient (csrc/convwgrad.hip) or the per-tap tiles.
  * Unknown names return SRK_E_UNSUPPORTED. */
 int srk_set_option(const char* name, int value);

@@ -118,3 +118,26 @@ def test_all_taps_conv_wgrad_matches_per_tap_tiles_on_the_model():
     for n in convs:
         rel = float((res[1][n] - res[0][n]).norm() / (res[0][n].norm() + 1e-12))
         assert rel <= 1e-4, f"{n}: {rel:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 192, 192), (16384, 576, 192), (4096 + 64 * 5, 192, 384)])
+def test_streaming_linear_wgrad_vs_torch_and_register_staged_kernel(ops, M, N, K):
+    """LDS-DMA ring variant of the 192x192 weight-gradient tile (swizzled transposing reads) against torch and against
+    the register-staged kernel; x carries a per-(row, column) pattern so that a wrong swizzle cannot cancel out."""
+    from tpu_superresolution_amd._lib import check, lib
+    torch.manual_seed(N + K)
+    y = bf(torch.randn(M, N) * 0.1)
+    x = bf(torch.randn(M, K) + 0.01 * torch.arange(K).float()[None, :] * ((torch.arange(M) % 7).float()[:, None] - 3.0))
+    ref_w = y.float().t() @ x.float()
+    ref_b = y.float().sum(0)
+    out = {}
+    for on in (1, 0):
+        check(lib().srk_set_option(b"wgrad_stream", on))
+        dw, db = ops.linear_wgrad_bf16(dev(y), dev(x))
+        out[on] = (dw.cpu(), db.cpu())
+    check(lib().srk_set_option(b"wgrad_stream", 1))
+    tol = 2e-3 * max(1.0, float(ref_w.abs().max()))
+    for on in (1, 0):
+        assert float((out[on][0] - ref_w).abs().max()) < tol
+        assert float((out[on][1] - ref_b).abs().max()) < 2e-2
+    assert float((out[1][0] - out[0][0]).abs().max()) < 1e-3 * max(1.0, float(ref_w.abs().max()))

@@ -1,0 +1,51 @@
+"""HBM traffic per launch of a kernel family from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+separate runs, as MI355X_MICROARCH.md prescribes):
+
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-name regex> <out.json>
+
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE reports half of wide coalesced reads; both in KiB)
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def per_kernel(d, counter):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).replace("void ", "")
+                agg[name].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    fetch_dir, write_dir, pattern, out = sys.argv[1:5]
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    rows, tot_b, tot_n = [], 0.0, 0
+    for name in sorted(fe):
+        if not re.search(pattern, name) or name not in wr:
+            continue
+        n = min(len(fe[name]), len(wr[name]))
+        b = (2.0 * sum(fe[name]) / len(fe[name]) + sum(wr[name]) / len(wr[name])) * 1024.0
+        rows.append({"kernel": name, "launches": n, "bytes_per_launch": b,
+                     "read_bytes_per_launch": 2.0 * sum(fe[name]) / len(fe[name]) * 1024.0,
+                     "write_bytes_per_launch": sum(wr[name]) / len(wr[name]) * 1024.0})
+        tot_b += b * n
+        tot_n += n
+    res = {"family": pattern, "avg_hbm_bytes_per_launch": tot_b / max(tot_n, 1), "launches_sampled": tot_n,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                     "(gfx950: FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)",
+           "per_kernel": rows}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != "per_kernel"}))
+    for r in rows:
+        print(f"  {r['kernel'][:70]:70s} {r['launches']:5d}  {r['bytes_per_launch'] / 1e6:8.1f} MB  (R {r['read_bytes_per_launch'] / 1e6:7.1f} / W {r['write_bytes_per_launch'] / 1e6:7.1f})")
+
+
+if __name__ == "__main__":
+    main()

@@ -239,6 +239,10 @@ int srk_set_option(const char* name, int value) {
     srk_gemm_stream_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "wgrad_stream") == 0) {
+    srk_wgrad_stream_enable(value);
+    return SRK_OK;
+  }
   if (strcmp(name, "conv_wgrad_taps") == 0) {
     srk_conv_wgrad_taps_enable(value);
     return SRK_OK;

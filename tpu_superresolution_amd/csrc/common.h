@@ -171,5 +171,26 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA (global -> LDS without a VGPR destination) and the waits that go with it
+// ---------------------------------------------------------------------------------------------
+// One wave instruction writes 64 x 16 B (or 64 x 4 B) CONTIGUOUS bytes at the wave-uniform LDS byte address
+// `lds_dst` (lane l lands at lds_dst + 16 l); the SOURCE address is per lane, which is where swizzles / gathers go.
+// The instruction counts on vmcnt like any vector-memory operation and retires in issue order.
+__device__ __forceinline__ void srk_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void srk_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// this wave's LDS operations complete, then the workgroup barrier -- WITHOUT the vmcnt(0) drain that
+// __syncthreads() implies while DMAs (or stores) are in flight
+__device__ __forceinline__ void srk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

@@ -32,4 +32,5 @@ int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);
 #define SRK_WGRAD_NOT_COVERED 1
 int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream);
 void srk_conv_wgrad_taps_enable(int on);
+void srk_wgrad_stream_enable(int on);   // LDS-DMA ring variant of the 192x192 linear tile (wgrad.hip)
 int srk_launch_wgrad_multi(const WgradParams* ps, int nprob, hipStream_t stream);

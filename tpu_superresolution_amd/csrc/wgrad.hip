@@ -179,6 +179,132 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
   }
 }
 
+// ---- streaming variant of the 192 x 192 linear tile -------------------------------------------------------------
+// Same tile, same MFMA schedule, but the 64-row Y / X chunks arrive by LDS-DMA into a 3-deep ring (48 KB per stage):
+// two chunks (96 KB per CU) are in flight while one is consumed, instead of the single register-staged chunk of
+// wgrad_kernel, whose load latency (~2 us under load) exceeded the 0.5 us of MFMA work per chunk.  No wave stores
+// inside the loop, so every wave's vmcnt sees only its own DMAs and the counted wait is exact; one raw barrier per
+// chunk.  A DMA writes lane-linear, which rules out the padded rows: rows are 384 B and the 32-byte column pairs
+// are XOR-swizzled with (row >> 1) & 3 on the SOURCE address -- the 8 consecutive rows a half-wave transposing
+// read touches then fall in 8 different 32-byte bank windows (row stride 384 B = 1.5 x 256 B).
+constexpr int WS_STAGE_ELEMS = 2 * 64 * 192;      // Y chunk + X chunk, bf16 elements
+constexpr int WS_RING = 3;
+
+__device__ __forceinline__ const bf16_t* tr_addr_swz(const bf16_t* tile, int rbase, int c0, int lane) {
+  const int ll = lane & 15;
+  const int row = rbase + (ll >> 2);
+  return tile + row * 192 + (((c0 >> 4) ^ ((row >> 1) & 3)) << 4) + ((ll & 3) << 2);
+}
+
+__global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) {
+  const int ntiles = mp.tile_begin[mp.nprob];
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bsplit = logical / ntiles, btile = logical - bsplit * ntiles;
+  int pi = 0;
+  while (pi + 1 < mp.nprob && btile >= mp.tile_begin[pi + 1]) ++pi;
+  const WgradParams& p = mp.p[pi];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+  const unsigned ring_base = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int ntn = p.N / 192;
+  const int bx = btile - mp.tile_begin[pi];
+  const int tn = bx % ntn, tk = bx / ntn;
+  const int n0 = tn * 192, k0 = tk * 192;
+  const int m_begin = bsplit * mp.m_per;
+  const int m_end = min(p.M, m_begin + mp.m_per);
+  const int nchunk = (m_end - m_begin) / 64;
+  if (nchunk <= 0) return;
+
+  // this wave's quarter of a stage image: 384 16-byte pieces of Y and of X (6 + 6 DMA instructions)
+  auto issue = [&](int ch) {
+    const int m0 = m_begin + ch * 64;
+    const unsigned dst = ring_base + (unsigned)((ch % WS_RING) * WS_STAGE_ELEMS * 2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = wave * 384 + i * 64 + lane;
+      const int row = q / 24, pos = q - row * 24;
+      const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
+      srk_glds16(p.Y + (long long)(m0 + row) * p.ldy + n0 + c * 8, __builtin_amdgcn_readfirstlane(dst + (wave * 384 + i * 64) * 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = wave * 384 + i * 64 + lane;
+      const int row = q / 24, pos = q - row * 24;
+      const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
+      srk_glds16(p.X + (long long)(m0 + row) * p.ldx + k0 + c * 8,
+                 __builtin_amdgcn_readfirstlane(dst + 64 * 192 * 2 + (wave * 384 + i * 64) * 16));
+    }
+  };
+
+  f32x4_t acc[6][6], accb[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.db != nullptr && tk == 0 && wk == 0;
+  const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  issue(0);
+  if (nchunk > 1) issue(1);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (ch + 1 < nchunk) srk_wait_vmcnt<12>(); else srk_wait_vmcnt<0>();   // chunk ch landed (ch+1 may be in flight)
+    srk_lds_barrier();                                                       // ... for every wave; MFMA(ch-1) done everywhere
+    if (ch + 2 < nchunk) issue(ch + 2);
+    const bf16_t* ys = ring + (ch % WS_RING) * WS_STAGE_ELEMS;
+    const bf16_t* xs = ys + 64 * 192;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yf[6], xf[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int c0 = wn * 96 + 16 * i;
+        const bf16x4_t lo = lds_tr_read(tr_addr_swz(ys, 32 * ks + 4 * g, c0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr_swz(ys, 32 * ks + 16 + 4 * g, c0, lane));
+        yf[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int c0 = wk * 96 + 16 * j;
+        const bf16x4_t lo = lds_tr_read(tr_addr_swz(xs, 32 * ks + 4 * g, c0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr_swz(xs, 32 * ks + 16 + 4 * g, c0, lane));
+        xf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int n = n0 + wn * 96 + 16 * i + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int k = k0 + wk * 96 + 16 * j + r16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + k, acc[i][j][e]);
+    }
+    if (do_bias && r16 == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.db + n + e, accb[i][e]);
+    }
+  }
+}
+
+int g_wgrad_stream = 1;
+
 template <int TA, int TB, bool CONV>
 int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 64 * ((64 * TA + 16) + (64 * TB + 16)) * sizeof(bf16_t);
@@ -212,6 +338,26 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   mp.m_per = m_per;
   splits = cdiv(M, m_per);
   const int fam = CONV ? FAM_WGRAD_CONV : FAM_WGRAD_LINEAR;
+  if constexpr (TA == 3 && TB == 3 && !CONV) {
+    bool ok = g_wgrad_stream && M % 64 == 0;
+    for (int i = 0; i < nprob; ++i) ok = ok && ps[i].ldy % 8 == 0 && ps[i].ldx % 8 == 0;
+    if (ok) {
+      constexpr int slds = WS_RING * WS_STAGE_ELEMS * 2;
+      static bool sconf = false;
+      if (!sconf) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, slds) !=
+            hipSuccess) {
+          srk_set_error("wgrad(stream): cannot reserve %d bytes of LDS", slds);
+          return SRK_E_LAUNCH;
+        }
+        sconf = true;
+      }
+      srk_probe_pre(fam, stream, flops, bytes);
+      hipLaunchKernelGGL(wgrad_stream_kernel, dim3(tiles * splits), dim3(256), slds, stream, mp);
+      srk_probe_post(fam, stream);
+      return srk_check_launch("wgrad(stream)");
+    }
+  }
   srk_probe_pre(fam, stream, flops, bytes);
   hipLaunchKernelGGL((wgrad_kernel<TA, TB, CONV>), dim3(tiles * splits), dim3(256), lds, stream, mp);
   srk_probe_post(fam, stream);
@@ -246,6 +392,8 @@ int validate(const WgradParams& p) {
 }
 
 }  // namespace
+
+void srk_wgrad_stream_enable(int on) { g_wgrad_stream = on ? 1 : 0; }
 
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
   int rc = validate(p);
