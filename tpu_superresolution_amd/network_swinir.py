@@ -362,7 +362,11 @@ class SwinIR(nn.Module):
         only in training mode with drop_path_rate > 0 (network_swinir.py:204, :276-277)."""
         if not self.training or self.drop_path_rate <= 0:
             return None
-        keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32, device=device).view(-1, 1, 1)
+        keep = getattr(self, "_keep_cache", None)
+        if keep is None or keep.device != torch.device(device):
+            # built once per device: a per-step host->device copy is a synchronous upload and cannot be graph-captured
+            keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32, device=device).view(-1, 1, 1)
+            self._keep_cache = keep
         u = torch.rand((len(self.dpr), 2, B), dtype=torch.float32, device=device)
         return ((u < keep).float() / keep).contiguous()
 
