@@ -23,7 +23,7 @@ def summary(path):
     for r in csv.DictReader(open(f)):
         if "gemm_stream" in r["Name"]:
             a = re.search(r"<(.*)>", r["Name"]).group(1).split(", ")
-            kind = "split" if "split_kernel" in r["Name"] else ("ks2" if a[3] == "true" else "sym")
+            kind = ("split" + a[3]) if "split_kernel" in r["Name"] else ("ks2" if a[3] == "true" else "sym")
             rows.append((NAMES.get(int(a[0]), a[0]), 64 * int(a[1]), int(a[2]), kind, int(r["Calls"]), float(r["AverageNs"]) / 1e3))
     for r in sorted(rows):
         print(f"{r[0]:9s} K={r[1]:3d} BM={r[2]:2d} {r[3]:12s} calls={r[4]:4d} avg={r[5]:7.1f} us")
@@ -45,9 +45,13 @@ def main():
         combos = [(bm, ks2, 0) for bm in (16, 32, 64) for ks2 in (0, 1)] + [(bm, -1, 1) for bm in (16, 32, 64)]
     elif mode == "split":
         combos = [(bm, -1, 1) for bm in (16, 32, 64)]
+    elif mode == "nb8":
+        combos = [(32, -1, 1, 8), (64, -1, 1, 8)]
     else:
         combos = [(0, -1, -1)]
-    for bm, ks2, split in combos:
+    for combo in combos:
+        bm, ks2, split = combo[:3]
+        check(lib().srk_set_option(b"gemm_stream_nb", combo[3] if len(combo) > 3 else 0))
         check(lib().srk_set_option(b"gemm_stream_bm", bm))
         check(lib().srk_set_option(b"gemm_stream_ks2", ks2))
         check(lib().srk_set_option(b"gemm_stream_split", split))

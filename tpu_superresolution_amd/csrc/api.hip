@@ -247,21 +247,27 @@ int srk_set_option(const char* name, int value) {
     srk_conv_wgrad_taps_enable(value);
     return SRK_OK;
   }
-  static int bm = 0, ks2 = -1, split = -1;
+  static int bm = 0, ks2 = -1, split = -1, nb = 0;
   if (strcmp(name, "gemm_stream_bm") == 0) {
     SRK_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, SRK_E_SHAPE, "gemm_stream_bm: 0/16/32/64");
     bm = value;
-    srk_gemm_stream_tune(bm, ks2, split);
+    srk_gemm_stream_tune(bm, ks2, split, nb);
+    return SRK_OK;
+  }
+  if (strcmp(name, "gemm_stream_nb") == 0) {
+    SRK_REQUIRE(value == 0 || value == 4 || value == 8, SRK_E_SHAPE, "gemm_stream_nb: 0/4/8");
+    nb = value;
+    srk_gemm_stream_tune(bm, ks2, split, nb);
     return SRK_OK;
   }
   if (strcmp(name, "gemm_stream_split") == 0) {
     split = value < 0 ? -1 : (value != 0);
-    srk_gemm_stream_tune(bm, ks2, split);
+    srk_gemm_stream_tune(bm, ks2, split, nb);
     return SRK_OK;
   }
   if (strcmp(name, "gemm_stream_ks2") == 0) {
     ks2 = value < 0 ? -1 : (value != 0);
-    srk_gemm_stream_tune(bm, ks2, split);
+    srk_gemm_stream_tune(bm, ks2, split, nb);
     return SRK_OK;
   }
   srk_set_error("srk_set_option: unknown option '%s'", name);

@@ -69,10 +69,28 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+
+// bf16x4 of gelu(v) / of v * gelu'(u): what the GELU / dGELU epilogues store.  These epilogues are VALU-bound on this
+// math; the derivative reuses erf's exp(-z^2) = exp(-x^2/2) for the Gaussian density instead of a second v_exp_f32.
+// (Packed-fp32 float2 versions of the polynomial were measured: no gain for GELU -- the two transcendentals per
+// element dominate -- so the scalar form stays.)
+__device__ __forceinline__ float dgelu_shared_exp(float x) {
+  const float z = x * 0.70710678118654752f;
+  const float ax = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);                 // = exp(-x^2 / 2)
+  const float erf = copysignf(1.0f - p * t * e, z);
+  return fmaf(x * 0.39894228040143268f, e, fmaf(0.5f, erf, 0.5f));
+}
+__device__ __forceinline__ uint2 gelu_pack4(float v0, float v1, float v2, float v3) {
+  return pack_bf4(gelu_f(v0), gelu_f(v1), gelu_f(v2), gelu_f(v3));
+}
+__device__ __forceinline__ uint2 dgelu_mul_pack4(float v0, float v1, float v2, float v3, float u0, float u1, float u2, float u3) {
+  return pack_bf4(v0 * dgelu_shared_exp(u0), v1 * dgelu_shared_exp(u1), v2 * dgelu_shared_exp(u2), v3 * dgelu_shared_exp(u3));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -86,4 +86,4 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
 #define SRK_NOT_COVERED 1
 int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream);
 void srk_gemm_stream_enable(int on);
-void srk_gemm_stream_tune(int bm, int ks2, int split);   // 0 / -1 / -1: defaults
+void srk_gemm_stream_tune(int bm, int ks2, int split, int nb);   // 0 / -1 / -1 / 0: defaults

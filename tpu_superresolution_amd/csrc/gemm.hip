@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       } else if constexpr (EP == EP_GELU) {
         *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v0, v1, v2, v3);
         *reinterpret_cast<uint2*>(p.outb2 + (long long)m * p.ldo + n) =
-            pack_bf4(gelu_f(v0), gelu_f(v1), gelu_f(v2), gelu_f(v3));
+            gelu_pack4(v0, v1, v2, v3);
       } else if constexpr (EP == EP_RES) {
         if (p.rowscale) {
           const float f = p.rowscale[m / p.rows_per_sample];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         unpack_bf2(u.x, u0, u1);
         unpack_bf2(u.y, u2, u3);
         *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) =
-            pack_bf4(v0 * dgelu_f(u0), v1 * dgelu_f(u1), v2 * dgelu_f(u2), v3 * dgelu_f(u3));
+            dgelu_mul_pack4(v0, v1, v2, v3, u0, u1, u2, u3);
       } else if constexpr (EP == EP_LRELU) {
         const float s = p.scale;
         *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) =

@@ -220,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           if (n >= p.N) continue;
           *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
           *reinterpret_cast<uint2*>(p.outb2 + (long long)m * p.ldo + n) =
-              pack_bf4(gelu_f(v[c].x), gelu_f(v[c].y), gelu_f(v[c].z), gelu_f(v[c].w));
+              gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w);
         }
       } else if constexpr (EP == EP_RES || EP == EP_RES_BF16) {
         const float f = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           unpack_bf2(ua.y, u2, u3);
           uint2 o;
           if constexpr (EP == EP_DGELU) {
-            o = pack_bf4(v[c].x * dgelu_f(u0), v[c].y * dgelu_f(u1), v[c].z * dgelu_f(u2), v[c].w * dgelu_f(u3));
+            o = dgelu_mul_pack4(v[c].x, v[c].y, v[c].z, v[c].w, u0, u1, u2, u3);
           } else {
             const float s = p.scale;
             o = pack_bf4(u0 > 0.f ? v[c].x : v[c].x * s, u1 > 0.f ? v[c].y : v[c].y * s, u2 > 0.f ? v[c].z : v[c].z * s,

@@ -225,11 +225,11 @@ __device__ __forceinline__ void ep_init(const GemmParams& p, int n0, int j16, Ep
 
 // row-major epilogue of one tile: T = accumulators [BM][SBNP], slot = the tile's LDS slot (A image, row operands, row
 // scalars, row maps); the calling wave (0..3) handles rows 16 ps + 4 wave + (lane >> 4)
-template <int EP, int KC, int BM>
+template <int EP, int KC, int BM, int NB = 4>
 __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const float* T, const unsigned char* slot, int m0, int n0,
                                                      int wave, int lane, EpState& st) {
   using C = StreamCfg<EP, KC, BM>;
-  constexpr int MF = BM / 16;
+  constexpr int MF = BM / (4 * NB);          // passes: NB waves x 4 rows per pass
   EP_STATE_REFS(st);
   const int sub = lane >> 4, j16 = lane & 15;
   // ---- row-major epilogue: 16 lanes per row, lane j16 holds columns 64c + 4 j16 .. +3 -----------------
@@ -238,7 +238,7 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
   const int* maps = reinterpret_cast<const int*>(auxf + 4 * 64);
 #pragma unroll
   for (int ps = 0; ps < MF; ++ps) {
-    const int lr = ps * 16 + wave * 4 + sub;
+    const int lr = ps * (4 * NB) + wave * 4 + sub;
     const int m = m0 + lr;
     float4 v[NC];
 #pragma unroll
@@ -267,7 +267,7 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
       for (int c = 0; c < NC; ++c) {
         const long long o = (long long)m * p.ldo + n0 + 64 * c + 4 * j16;
         *reinterpret_cast<uint2*>(p.outb + o) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
-        *reinterpret_cast<uint2*>(p.outb2 + o) = pack_bf4(gelu_f(v[c].x), gelu_f(v[c].y), gelu_f(v[c].z), gelu_f(v[c].w));
+        *reinterpret_cast<uint2*>(p.outb2 + o) = gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w);
       }
     } else if constexpr (EP == EP_DGELU) {
 #pragma unroll
@@ -277,7 +277,7 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
         unpack_bf2(ua.x, u0, u1);
         unpack_bf2(ua.y, u2, u3);
         *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) =
-            pack_bf4(v[c].x * dgelu_f(u0), v[c].y * dgelu_f(u1), v[c].z * dgelu_f(u2), v[c].w * dgelu_f(u3));
+            dgelu_mul_pack4(v[c].x, v[c].y, v[c].z, v[c].w, u0, u1, u2, u3);
       }
     } else if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
       const long long t_ = maps[lr];
@@ -498,8 +498,8 @@ struct SplitCfg {
   static_assert(C::P * (R - 3) <= 63, "vmcnt overflow");
 };
 
-template <int EP, int KC, int BM>
-__global__ __launch_bounds__(512) void gemm_stream_split_kernel(const GemmParams p, int nchunk, int groups_per_xcd) {
+template <int EP, int KC, int BM, int NB>
+__global__ __launch_bounds__(64 * (NB + 4)) void gemm_stream_split_kernel(const GemmParams p, int nchunk, int groups_per_xcd) {
   using C = StreamCfg<EP, KC, BM>;
   using S = SplitCfg<EP, KC, BM>;
   constexpr int K = C::K, R = S::R, MF = BM / 16, KST = K / 32;
@@ -520,12 +520,12 @@ __global__ __launch_bounds__(512) void gemm_stream_split_kernel(const GemmParams
   const int nt = gi < ntm ? (ntm - gi + Gm - 1) / Gm : 0;
   if (nt == 0) return;
   if constexpr (EP == EP_LNBWD) {
-    for (int i = tid; i < 2 * SBN; i += 512) colred[i] = 0.f;
+    for (int i = tid; i < 2 * SBN; i += 64 * (NB + 4)) colred[i] = 0.f;
   }
 
-  if (wave >= 4) {
+  if (wave >= NB) {
     // =================================== front waves: DMA + MFMA ===================================
-    const int lw = wave - 4, wn = lw;
+    const int lw = wave - NB, wn = lw;
     bf16x8_t wf[3][KST];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm_stream_split_kernel(const GemmParams
       lds_barrier();                        // barrier(i): T[(i-1) & 1] holds tile i-1
       if (i > 0) {
         const int t = i - 1;
-        stream_epilogue_tile<EP, KC, BM>(p, reinterpret_cast<const float*>(smem + (t & 1) * C::T_BYTES),
+        stream_epilogue_tile<EP, KC, BM, NB>(p, reinterpret_cast<const float*>(smem + (t & 1) * C::T_BYTES),
                                          smem + SLOTS_OFF + (t % R) * C::SLOT, (gi + t * Gm) * BM, n0, wave, lane, st);
       }
     }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm_stream_split_kernel(const GemmParams
   }
   if constexpr (EP == EP_LNBWD) {
     lds_barrier();
-    for (int n = tid; n < p.ln_C; n += 512) {
+    for (int n = tid; n < p.ln_C; n += 64 * (NB + 4)) {
       atomicAdd(p.ln_dgamma + n, colred[n]);
       atomicAdd(p.ln_dbeta + n, colred[SBN + n]);
     }
@@ -606,6 +606,7 @@ int g_num_cus = 0;
 int g_tune_bm = 0;             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
 int g_tune_ks2 = -1;           // split K over the two wave groups: 0/1, -1 = default
 int g_tune_split = -1;         // role-split kernel (MFMA on the loader waves): 0/1, -1 = default
+int g_tune_nb = 0;             // role-split kernel: epilogue waves 4/8, 0 = default
 
 template <typename KernelT>
 int stream_configure(KernelT kernel, int lds, int* state) {
@@ -629,20 +630,20 @@ int stream_configure(KernelT kernel, int lds, int* state) {
   return SRK_OK;
 }
 
-template <int EP, int KC, int BM>
+template <int EP, int KC, int BM, int NB>
 int launch_split(const GemmParams& p, hipStream_t stream) {
   using S = SplitCfg<EP, KC, BM>;
-  if constexpr (!S::VALID) {
+  if constexpr (!S::VALID || BM % (4 * NB) != 0 || (NB == 8 && (KC > 3 || EP == EP_LNBWD))) {   // 12 waves: <= 168 VGPRs
     return SRK_NOT_COVERED;
   } else {
     static int configured = 0;     // 1 usable, -1 not usable
-    const int rc = stream_configure(&gemm_stream_split_kernel<EP, KC, BM>, S::LDS, &configured);
+    const int rc = stream_configure(&gemm_stream_split_kernel<EP, KC, BM, NB>, S::LDS, &configured);
     if (rc) return rc;
     if (configured < 0) return SRK_NOT_COVERED;
     const int nchunk = p.N / SBN;
     const int per_xcd = g_num_cus / 8;
     srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
-    hipLaunchKernelGGL((gemm_stream_split_kernel<EP, KC, BM>), dim3(per_xcd * 8), dim3(512), S::LDS, stream, p, nchunk, per_xcd / nchunk);
+    hipLaunchKernelGGL((gemm_stream_split_kernel<EP, KC, BM, NB>), dim3(per_xcd * 8), dim3(64 * (NB + 4)), S::LDS, stream, p, nchunk, per_xcd / nchunk);
     srk_probe_post(FAM_GEMM_LINEAR, stream);
     return srk_check_launch("gemm(stream-split)");
   }
@@ -677,10 +678,15 @@ int launch_cfg(const GemmParams& p, hipStream_t stream, int bm, bool ks2) {
 }
 
 template <int EP, int KC>
-int launch_split_bm(const GemmParams& p, hipStream_t stream, int bm) {
-  if (bm == 16) return launch_split<EP, KC, 16>(p, stream);
-  if (bm == 32) return launch_split<EP, KC, 32>(p, stream);
-  if (bm == 64) return launch_split<EP, KC, 64>(p, stream);
+int launch_split_bm(const GemmParams& p, hipStream_t stream, int bm, int nb) {
+  if (nb == 8) {
+    if (bm == 32) return launch_split<EP, KC, 32, 8>(p, stream);
+    if (bm == 64) return launch_split<EP, KC, 64, 8>(p, stream);
+    return SRK_NOT_COVERED;
+  }
+  if (bm == 16) return launch_split<EP, KC, 16, 4>(p, stream);
+  if (bm == 32) return launch_split<EP, KC, 32, 4>(p, stream);
+  if (bm == 64) return launch_split<EP, KC, 64, 4>(p, stream);
   return SRK_NOT_COVERED;
 }
 
@@ -689,6 +695,7 @@ struct StreamChoice {
   int bm;        // rows per tile
   bool ks2;      // symmetric kernel: split K over the two wave groups
   bool split;    // role-split kernel
+  int nb = 4;    // role-split kernel: epilogue (back) waves, 4 or 8
 };
 
 template <int EP, int KC>
@@ -697,8 +704,9 @@ int pick(const GemmParams& p, hipStream_t stream, StreamChoice def) {
   if (g_tune_bm) c.bm = g_tune_bm;
   if (g_tune_ks2 >= 0) c.ks2 = g_tune_ks2 != 0;
   if (g_tune_split >= 0) c.split = g_tune_split != 0;
-  int rc = c.split ? launch_split_bm<EP, KC>(p, stream, c.bm) : launch_cfg<EP, KC>(p, stream, c.bm, c.ks2);
-  if (rc == SRK_NOT_COVERED) rc = def.split ? launch_split_bm<EP, KC>(p, stream, def.bm) : launch_cfg<EP, KC>(p, stream, def.bm, def.ks2);
+  if (g_tune_nb > 0) c.nb = g_tune_nb;
+  int rc = c.split ? launch_split_bm<EP, KC>(p, stream, c.bm, c.nb) : launch_cfg<EP, KC>(p, stream, c.bm, c.ks2);
+  if (rc == SRK_NOT_COVERED) rc = def.split ? launch_split_bm<EP, KC>(p, stream, def.bm, def.nb) : launch_cfg<EP, KC>(p, stream, def.bm, def.ks2);
   return rc;
 }
 
@@ -713,10 +721,11 @@ int dispatch_k(const GemmParams& p, hipStream_t stream, StreamChoice k192, Strea
 
 // 1: use the streaming kernel where it applies (default); 0: always use the tile kernel of gemm.hip
 void srk_gemm_stream_enable(int on) { g_stream_enabled = on ? 1 : 0; }
-void srk_gemm_stream_tune(int bm, int ks2, int split) {
+void srk_gemm_stream_tune(int bm, int ks2, int split, int nb) {
   g_tune_bm = bm;
   g_tune_ks2 = ks2;
   g_tune_split = split;
+  g_tune_nb = nb;
 }
 
 // Returns SRK_NOT_COVERED when the streaming kernel does not cover this problem (the caller then uses the tile kernel).
