@@ -93,15 +93,18 @@ int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream);
  * family (1 linear GEMM, 2 conv GEMM, 3 linear wgrad, 4 conv wgrad, 5 attention fwd, 6 attention bwd) is bracketed
  * by HIP events on its own stream.  srk_probe_end synchronises those events and returns the summed kernel time,
  * the summed ALGORITHMIC (un-padded) FLOPs and HBM bytes (each operand read / result written once) and the
- * launch count.  Not thread-safe; one probe at a time. */
+ * launch count.  Not thread-safe; one probe at a time.  srk_set_option("probe_stride", s) brackets only every s-th
+ * launch of the family (a uniform sample when s is coprime with the per-block launch pattern): the two event records
+ * per launch otherwise cost a few percent of a step. */
 int srk_probe_begin(int family, int capacity);
 int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches);
 
 /* Kernel-selection switches (A/B testing; results are equivalent up to fp32 summation order).
  *   "gemm_stream" 1 (default) / 0: use the persistent LDS-DMA GEMM (csrc/gemm_stream.hip) for the block GEMMs it
  *   covers, or always the tile-per-workgroup GEMM (csrc/gemm.hip).  Env SRK_GEMM_STREAM=0 sets the initial value.
- *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1: tile-shape overrides of that
- *   kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
+ *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1, "gemm_stream_nb" 0/4/8:
+ *   tile-shape overrides of that kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
+ *   "probe_stride" 1..1024: see srk_probe_begin.
  *   "wgrad_stream" 1 (default) / 0: LDS-DMA ring variant of the 192x192 linear weight-gradient tile or the
  *   register-staged one (both in csrc/wgrad.hip).
  *   "conv_wgrad_taps" 1 (default) / 0: all-taps conv weight gradient (csrc/convwgrad.hip) or the per-tap tiles.

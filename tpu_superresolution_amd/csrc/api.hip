@@ -31,20 +31,28 @@ struct Probe {
   int family = 0;
   bool active = false;
   size_t count = 0;
+  size_t seen = 0;          // launches of the family since probe_begin
+  int stride = 1;           // bracket every stride-th launch (option "probe_stride"): the two event records per launch
+                            // cost ~2.5 us of stream time each, which matters at several hundred launches per step
+  bool sampling = false;    // the launch between the current pre / post is a sampled one
   double flops = 0.0, bytes = 0.0;
   std::vector<hipEvent_t> ev0, ev1;
 } g_probe;
 }  // namespace
 
 void srk_probe_pre(int family, hipStream_t stream, double flops, double bytes) {
+  g_probe.sampling = false;
   if (!g_probe.active || family != g_probe.family || g_probe.count >= g_probe.ev0.size()) return;
+  if ((g_probe.seen++ % (size_t)g_probe.stride) != 0) return;
+  g_probe.sampling = true;
   hipEventRecord(g_probe.ev0[g_probe.count], stream);
   g_probe.flops += flops;
   g_probe.bytes += bytes;
 }
 
 void srk_probe_post(int family, hipStream_t stream) {
-  if (!g_probe.active || family != g_probe.family || g_probe.count >= g_probe.ev0.size()) return;
+  if (!g_probe.sampling || !g_probe.active || family != g_probe.family) return;
+  g_probe.sampling = false;
   hipEventRecord(g_probe.ev1[g_probe.count], stream);
   ++g_probe.count;
 }
@@ -208,6 +216,7 @@ int srk_probe_begin(int family, int capacity) {
   }
   g_probe.family = family;
   g_probe.count = 0;
+  g_probe.seen = 0;
   g_probe.flops = 0.0;
   g_probe.bytes = 0.0;
   g_probe.active = true;
@@ -237,6 +246,11 @@ int srk_set_option(const char* name, int value) {
   REQ_PTR(name);
   if (strcmp(name, "gemm_stream") == 0) {
     srk_gemm_stream_enable(value);
+    return SRK_OK;
+  }
+  if (strcmp(name, "probe_stride") == 0) {
+    SRK_REQUIRE(value >= 1 && value <= 1024, SRK_E_SHAPE, "probe_stride: 1..1024");
+    g_probe.stride = value;
     return SRK_OK;
   }
   if (strcmp(name, "wgrad_stream") == 0) {
