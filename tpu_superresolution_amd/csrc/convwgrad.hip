@@ -97,14 +97,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(const WgradParams 
   const bool do_bias = p.db != nullptr && tk == 0 && wave == 0;
   const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   // this wave's nine column groups: cg = 9 wave + q -> (tap = cg / 4, k-fragment = cg % 4)
-  int xbase[9], xcol[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int cg = 9 * wave + q;
-    const int tap = cg >> 2, kf = cg & 3;
-    xbase[q] = (tap / 3) * HALO + (tap % 3);      // halo row of pixel (x0 + 0) shifted by (dy, dx)
-    xcol[q] = 16 * kf;
-  }
 
   load_stage(c_begin);
   store_stage(0);
@@ -126,8 +118,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(const WgradParams 
       }
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SP, xbase[q] + 32 * ks + 4 * g, xcol[q], lane));
-        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SP, xbase[q] + 32 * ks + 16 + 4 * g, xcol[q], lane));
+        const int cg = 9 * wave + q;
+        const int tap = cg >> 2;
+        const int xb = (tap / 3) * HALO + (tap % 3);        // halo row of pixel x0 shifted by this tap's (dy, dx)
+        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SP, xb + 32 * ks + 4 * g, 16 * (cg & 3), lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SP, xb + 32 * ks + 16 + 4 * g, 16 * (cg & 3), lane));
         const bf16x8_t xf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf, acc[i][q], 0, 0, 0);
@@ -187,6 +182,162 @@ int launch_taps(const WgradParams& p, hipStream_t stream) {
   return srk_check_launch("conv wgrad (all taps)");
 }
 
+// ---- image-head variant: Cout <= 16, dY in fp32 ------------------------------------------------------------------
+// Weight gradient of the convs that produce the image (conv_last 64 -> 3 at HR resolution, UpsampleOneStep): same
+// all-taps structure with ONE 16-row n-fragment.  dY arrives as fp32 [pixels][COP] (the L1-loss gradient) and is split
+// into bf16 hi + lo on the way into LDS (two MFMAs per fragment pair, ~2^-17 relative), so this path keeps fp32-grade
+// precision while the 2 M-pixel reduction runs on the matrix cores instead of the VALU (0.9 ms -> see profiles/).
+template <int COP>
+__global__ __launch_bounds__(256) void smallconv_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gy,
+                                                                   float* __restrict__ dW, float* __restrict__ db, int B, int H, int W,
+                                                                   int Cin, int CinP, int Co, int ntiles, int chunks_per) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Yh = reinterpret_cast<bf16_t*>(smem);      // [2][CT][16]
+  bf16_t* Yl = Yh + 2 * CT * 16;                     // [2][CT][16]
+  bf16_t* Xs = Yl + 2 * CT * 16;                     // [2][XROWS][SP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bsplit = logical / ntiles, tk = logical - bsplit * ntiles;
+  const int k0 = tk * 64;
+  const int M = B * H * W;
+  const int c_begin = bsplit * chunks_per;
+  const int c_end = min(M / CT, c_begin + chunks_per);
+  if (c_begin >= c_end) return;
+  const int hw = H * W;
+  for (int i = tid; i < 2 * 2 * CT * 16 / 2; i += 256) reinterpret_cast<unsigned*>(Yh)[i] = 0u;   // columns >= COP stay zero
+
+  constexpr int YP = CT * COP / 4;          // float4 pieces of dY per chunk (64 or 256)
+  float4 ry = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint4 rx[XPIECES];
+  auto load_stage = [&](int ch) {
+    const int m0 = ch * CT;
+    const int b = m0 / hw, rem = m0 - b * hw;
+    const int y = rem / W, x0 = rem - y * W;
+    if (tid < YP) ry = *reinterpret_cast<const float4*>(gy + (long long)m0 * COP + tid * 4);
+#pragma unroll
+    for (int t = 0; t < XPIECES; ++t) {
+      const int pid = tid + 256 * t;
+      const int hr = pid >> 3, c8 = pid & 7;
+      const int rr = hr / HALO, px = hr - rr * HALO;
+      const int yy = y + rr - 1, xx = x0 + px - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (hr < XROWS && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v = *reinterpret_cast<const uint4*>(x + ((long long)(b * H + yy) * W + xx) * CinP + k0 + c8 * 8);
+      rx[t] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    if (tid < YP) {
+      const int row = tid / (COP / 4), f4 = tid % (COP / 4);
+      const float gv[4] = {ry.x, ry.y, ry.z, ry.w};
+      float hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = bf2f(f2bf(gv[e]));
+        lo[e] = gv[e] - hi[e];
+      }
+      *reinterpret_cast<uint2*>(Yh + (buf * CT + row) * 16 + f4 * 4) = pack_bf4(hi[0], hi[1], hi[2], hi[3]);
+      *reinterpret_cast<uint2*>(Yl + (buf * CT + row) * 16 + f4 * 4) = pack_bf4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    bf16_t* xs = Xs + buf * XROWS * SP;
+#pragma unroll
+    for (int t = 0; t < XPIECES; ++t) {
+      const int pid = tid + 256 * t;
+      if (pid < XROWS * 8) *reinterpret_cast<uint4*>(xs + (pid >> 3) * SP + (pid & 7) * 8) = rx[t];
+    }
+  };
+
+  f32x4_t acc[9], accb = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 9; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = db != nullptr && tk == 0 && wave == 0;
+  const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  load_stage(c_begin);
+  __syncthreads();                                   // the zero fill above is complete
+  store_stage(0);
+  __syncthreads();
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int buf = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) load_stage(ch + 1);
+    const bf16_t* yh = Yh + buf * CT * 16;
+    const bf16_t* yl = Yl + buf * CT * 16;
+    const bf16_t* xs = Xs + buf * XROWS * SP;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yfh, yfl;
+      {
+        const bf16x4_t lo = lds_tr_read(tr_addr(yh, 16, 32 * ks + 4 * g, 0, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(yh, 16, 32 * ks + 16 + 4 * g, 0, lane));
+        yfh = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x4_t lo2 = lds_tr_read(tr_addr(yl, 16, 32 * ks + 4 * g, 0, lane));
+        const bf16x4_t hi2 = lds_tr_read(tr_addr(yl, 16, 32 * ks + 16 + 4 * g, 0, lane));
+        yfl = bf16x8_t{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int cg = 9 * wave + q;
+        const int tap = cg >> 2, kf = cg & 3;
+        const int xb = (tap / 3) * HALO + (tap % 3);
+        const bf16x4_t lo = lds_tr_read(tr_addr(xs, SP, xb + 32 * ks + 4 * g, 16 * kf, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr(xs, SP, xb + 32 * ks + 16 + 4 * g, 16 * kf, lane));
+        const bf16x8_t xf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yfh, xf, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yfl, xf, acc[q], 0, 0, 0);
+      }
+      if (do_bias) {
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yfh, ones, accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yfl, ones, accb, 0, 0, 0);
+      }
+    }
+    if (ch + 1 < c_end) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // acc[q][e] = dW[n = 4g + e][k = k0 + 16 kf + r16][tap]   (state_dict layout [Cout][Cin][3][3])
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int cg = 9 * wave + q;
+    const int tap = cg >> 2, k = k0 + 16 * (cg & 3) + r16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = 4 * g + e;
+      if (n < Co && k < Cin) atomicAdd(dW + ((long long)(n * Cin) + k) * 9 + tap, acc[q][e]);
+    }
+  }
+  if (do_bias && r16 == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * g + e < Co) atomicAdd(db + 4 * g + e, accb[e]);
+  }
+}
+
+template <int COP>
+int launch_smallconv_mfma(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP, int Co,
+                          hipStream_t stream) {
+  constexpr size_t lds = (size_t)(2 * 2 * CT * 16 + 2 * XROWS * SP) * sizeof(bf16_t);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_wgrad_mfma_kernel<COP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      srk_set_error("smallconv wgrad: cannot reserve %zu bytes of LDS", lds);
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  const int tiles = CinP / 64;
+  const int nchunks = (B * H * W) / CT;
+  int splits = 512 / tiles;                       // two workgroups per CU
+  if (splits > nchunks) splits = nchunks;
+  const int chunks_per = cdiv(nchunks, splits);
+  splits = cdiv(nchunks, chunks_per);
+  hipLaunchKernelGGL((smallconv_wgrad_mfma_kernel<COP>), dim3(tiles * splits), dim3(256), lds, stream, x, gy, dW, db, B, H, W, Cin, CinP, Co,
+                     tiles, chunks_per);
+  return srk_check_launch("smallconv wgrad (mfma)");
+}
+
 }  // namespace
 
 void srk_conv_wgrad_taps_enable(int on) { g_taps_enabled = on ? 1 : 0; }
@@ -200,4 +351,13 @@ int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream) {
   }
   if (p.ldy % 8 != 0) return SRK_WGRAD_NOT_COVERED;
   return launch_taps<false>(p, stream);
+}
+
+// image-head convs (Cout <= 16, fp32 dY): SRK_WGRAD_NOT_COVERED -> the VALU kernel of misc.hip
+int srk_launch_smallconv_wgrad_mfma(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP,
+                                    int Co, int CoP, hipStream_t stream) {
+  if (!g_taps_enabled || W % CT != 0 || CinP % 64 != 0 || Co > CoP || ((long long)B * H * W) % CT != 0) return SRK_WGRAD_NOT_COVERED;
+  if (CoP == 4) return launch_smallconv_mfma<4>(x, gy, dW, db, B, H, W, Cin, CinP, Co, stream);
+  if (CoP == 16) return launch_smallconv_mfma<16>(x, gy, dW, db, B, H, W, Cin, CinP, Co, stream);
+  return SRK_WGRAD_NOT_COVERED;
 }

@@ -3,6 +3,7 @@
 // processing, the 3-channel stem conv, small-Cout conv gradients, L1 loss, fused AdamW + global-norm
 // clip, and the on-device probe of the transposing LDS read.
 #include "pack.h"
+#include "wgrad.h"
 
 namespace {
 
@@ -696,6 +697,10 @@ int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, floa
                                int CinP, int Co, int CoP, hipStream_t stream) {
   SRK_REQUIRE(Co <= CoP && (CoP == 4 || CoP == 16) && CinP <= 256 && CinP % 64 == 0, SRK_E_SHAPE,
               "smallconv wgrad: Co=%d CoP=%d CinP=%d", Co, CoP, CinP);
+  {
+    const int rc = srk_launch_smallconv_wgrad_mfma(x, gy, dW, db, B, H, W, Cin, CinP, Co, CoP, stream);   // W % 64 == 0: matrix cores
+    if (rc != SRK_WGRAD_NOT_COVERED) return rc;
+  }
   const int PG = 256 / CinP;
   const int threads = CinP * PG;
   const size_t stage = (size_t)64 * 9 * CoP, red = (size_t)PG * 9 * CoP * CinP;
