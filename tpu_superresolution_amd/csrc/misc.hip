@@ -684,6 +684,10 @@ int srk_launch_img_grad_prep(const float* dpred, float* gy, int B, int Cimg, int
 int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP,
                                int Co, int CoP, hipStream_t stream) {
   SRK_REQUIRE(Co <= 16 && Co <= CoP, SRK_E_SHAPE, "smallconv dgrad: Co=%d", Co);
+  {
+    const int rc = srk_launch_imghead_dgrad_mfma(gy, wgt, dx, B, H, W, Cin, CinP, Co, CoP, stream);   // Cout <= 4, Cin <= 64: matrix cores
+    if (rc != SRK_WGRAD_NOT_COVERED) return rc;
+  }
   const size_t lds = (size_t)(9 * Co * CinP + 16 * 9 * CoP) * sizeof(float);
   SRK_REQUIRE(lds <= 64 * 1024, SRK_E_SHAPE, "smallconv dgrad: LDS %zu too large", lds);
   const long long npix = (long long)B * H * W;

@@ -34,5 +34,7 @@ int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream);
 void srk_conv_wgrad_taps_enable(int on);
 int srk_launch_smallconv_wgrad_mfma(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP, int Co,
                                     int CoP, hipStream_t stream);
+int srk_launch_imghead_dgrad_mfma(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP, int Co, int CoP,
+                                  hipStream_t stream);
 void srk_wgrad_stream_enable(int on);   // LDS-DMA ring variant of the 192x192 linear tile (wgrad.hip)
 int srk_launch_wgrad_multi(const WgradParams* ps, int nprob, hipStream_t stream);
