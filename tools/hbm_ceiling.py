@@ -16,11 +16,11 @@ def timeit(fn, n=20):
 for mb in (100, 400, 1600):
     n = mb * 1024 * 1024 // 4
     a = torch.rand(n, device="cuda"); b = torch.rand(n, device="cuda"); c = torch.empty(n, device="cuda")
-    t = timeit(lambda: c.copy_(a));            print(f"{mb:5d} MB copy   (1R:1W): {t:8.1f} us  {2 * mb * 1.048576 / t:6.2f} TB/s".replace("TB/s", "GB/ms"), flush=True)
-    t = timeit(lambda: torch.add(a, b, out=c)); print(f"{mb:5d} MB add    (2R:1W): {t:8.1f} us  {3 * mb * 1.048576 / t * 1e-3:6.2f} TB/s", flush=True)
-    t = timeit(lambda: a.add_(b));             print(f"{mb:5d} MB add_   (2R:1W in place): {t:8.1f} us  {3 * mb * 1.048576 / t * 1e-3:6.2f} TB/s", flush=True)
-    t = timeit(lambda: c.fill_(1.0));          print(f"{mb:5d} MB fill   (0R:1W): {t:8.1f} us  {mb * 1.048576 / t * 1e-3:6.2f} TB/s", flush=True)
-    t = timeit(lambda: a.sum());               print(f"{mb:5d} MB sum    (1R:0W): {t:8.1f} us  {mb * 1.048576 / t * 1e-3:6.2f} TB/s", flush=True)
+    t = timeit(lambda: c.copy_(a));            print(f"{mb:5d} MB copy   (1R:1W): {t:8.1f} us  {2 * mb * 1.048576 / t:6.2f} TB/s", flush=True)
+    t = timeit(lambda: torch.add(a, b, out=c)); print(f"{mb:5d} MB add    (2R:1W): {t:8.1f} us  {3 * mb * 1.048576 / t:6.2f} TB/s", flush=True)
+    t = timeit(lambda: a.add_(b));             print(f"{mb:5d} MB add_   (2R:1W in place): {t:8.1f} us  {3 * mb * 1.048576 / t:6.2f} TB/s", flush=True)
+    t = timeit(lambda: c.fill_(1.0));          print(f"{mb:5d} MB fill   (0R:1W): {t:8.1f} us  {mb * 1.048576 / t:6.2f} TB/s", flush=True)
+    t = timeit(lambda: a.sum());               print(f"{mb:5d} MB sum    (1R:0W): {t:8.1f} us  {mb * 1.048576 / t:6.2f} TB/s", flush=True)
     del a, b, c
 
 # pure-read ceiling with a hand-written streaming reduction (libsrk srk_grad_sumsq: float4 loads, grid-stride)
