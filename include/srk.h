@@ -107,7 +107,8 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   "probe_stride" 1..1024: see srk_probe_begin.
  *   "wgrad_stream" 1 (default) / 0: LDS-DMA ring variant of the 192x192 linear weight-gradient tile or the
  *   register-staged one (both in csrc/wgrad.hip).
- *   "conv_wgrad_taps" 1 (default) / 0: all-taps conv weight gradient (csrc/convwgrad.hip) or the per-tap tiles.
+ *   "conv_wgrad_taps" 2 (default) / 1 / 0: all-taps conv weight gradient with the LDS-DMA ring / register-staged
+ *   (csrc/convwgrad.hip, incl. the MFMA image-head kernels), or the per-tap tiles of wgrad.hip + the VALU image head.
  * Unknown names return SRK_E_UNSUPPORTED. */
 int srk_set_option(const char* name, int value);
 

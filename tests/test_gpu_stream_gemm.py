@@ -110,16 +110,18 @@ def test_all_taps_conv_wgrad_matches_per_tap_tiles_on_the_model(upsampler):
     x = torch.rand(4, 3, 64, 64, generator=gen).cuda()
     t = torch.rand(4, 3, 128, 128, generator=gen).cuda()
     res = {}
-    for on in (1, 0):
+    for on in (2, 1, 0):          # 2: all-taps LDS-DMA ring (default), 1: all-taps register-staged, 0: per-tap tiles / VALU head
         check(lib().srk_set_option(b"conv_wgrad_taps", on))
         m = build(cfg, sd, train=True)
         torch.nn.functional.l1_loss(m(x), t).backward()
         torch.cuda.synchronize()
         res[on] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
-    check(lib().srk_set_option(b"conv_wgrad_taps", 1))
+    check(lib().srk_set_option(b"conv_wgrad_taps", 2))
     convs = [n for n in res[0] if (".conv." in n or n.startswith(("conv_", "upsample."))) and n != "conv_first.weight"]
     assert len(convs) >= (8 if upsampler == "pixelshuffle" else 5)
     for n in convs:
+        rel21 = float((res[2][n] - res[1][n]).norm() / (res[1][n].norm() + 1e-12))
+        assert rel21 <= 1e-5, f"{n}: ring vs register-staged {rel21:.3e}"      # same operands, same MFMA order
         rel = float((res[1][n] - res[0][n]).norm() / (res[0][n].norm() + 1e-12))
         # the image-head convs see identical operands in both runs; everything upstream of them also sees the bf16 flips
         # that the MFMA image-head dgrad (hi + lo split) and the fp32 VALU dgrad produce in their bf16 result

@@ -182,6 +182,190 @@ int launch_taps(const WgradParams& p, hipStream_t stream) {
   return srk_check_launch("conv wgrad (all taps)");
 }
 
+// ---- LDS-DMA ring variant of the all-taps kernel -----------------------------------------------------------------------
+// Same tile and MFMA schedule as conv_wgrad_taps_kernel, but the dY rows and the X halo of a 64-pixel run arrive by
+// LDS-DMA into a 4-deep ring (33.5 KB per stage, three runs in flight) instead of one register-staged run: the
+// register-staged loop was bound by its load latency (2.4 us per run for 0.5 us of MFMA work).  Out-of-image halo
+// pixels are DMA'd from a zero page (the source address is per lane), rows are unpadded 128-byte pixel rows whose
+// 32-byte column pairs are XOR-swizzled with (row >> 1) & 3 on the source address (conflict-free transposing reads for
+// any 8 consecutive rows), no wave stores inside the loop (exact counted vmcnt), one raw barrier per run.
+__device__ uint4 g_zero_page[8];     // 128 zero bytes: DMA source for out-of-image pixels
+
+constexpr int TD_YROWS = CT, TD_STAGE_ROWS = CT + XROWS;       // 64 + 198 rows of 64 bf16
+constexpr int TD_STAGE_BYTES = TD_STAGE_ROWS * 128;
+constexpr int TD_RING = 4;
+constexpr int TD_PIECES = TD_STAGE_ROWS * 8;                   // 16-byte pieces per stage (2096)
+constexpr int TD_PPW = TD_PIECES / 4;                          // per wave (524)
+constexpr int TD_NI = (TD_PPW + 63) / 64;                      // DMA instructions per wave per run (9)
+
+__device__ __forceinline__ const bf16_t* tr_addr_swz64(const bf16_t* tile, int rbase, int c0, int lane) {
+  const int ll = lane & 15;
+  const int row = rbase + (ll >> 2);
+  return tile + row * 64 + (((c0 >> 4) ^ ((row >> 1) & 3)) << 4) + ((ll & 3) << 2);
+}
+
+template <bool SHUF>
+__global__ __launch_bounds__(256) void conv_wgrad_taps_dma_kernel(const WgradParams p, int ntiles, int chunks_per) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned ring_base = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bsplit = logical / ntiles, btile = logical - bsplit * ntiles;
+  const int ntn = p.N / 64;
+  const int tn = btile % ntn, tk = btile / ntn;
+  const int n0 = tn * 64, k0 = tk * 64;
+  const int c_begin = bsplit * chunks_per;
+  const int c_end = min(p.M / CT, c_begin + chunks_per);
+  if (c_begin >= c_end) return;
+  const int hw = p.H * p.W;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // stage image: rows 0..63 = dY of the run's pixels, rows 64.. = X halo (3 rows x 66 pixels); this wave moves pieces
+  // [wave * TD_PPW, (wave + 1) * TD_PPW).  Which piece a lane moves in DMA instruction i never changes, so everything
+  // that depends on the lane only is computed once: the element offset relative to the run's first pixel and, for halo
+  // pieces, (halo row, halo pixel) for the per-run bounds test.  Per run and instruction this leaves two compares, a
+  // select and a 64-bit add (the address math otherwise costs more issue slots than the 72 MFMAs of the run).
+  int loff[TD_NI];          // element offset of the piece relative to the run base (dY or X)
+  int lrp[TD_NI];           // dY piece: -1; halo piece: (rr << 8) | px
+#pragma unroll
+  for (int i = 0; i < TD_NI; ++i) {
+    const int qq = wave * TD_PPW + i * 64 + lane;
+    const int row = qq >> 3, pos = qq & 7;
+    const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);           // logical 16-byte piece of this LDS position
+    if (row < TD_YROWS) {
+      lrp[i] = -1;
+      if constexpr (SHUF) {
+        const int nn = n0 + c * 8;
+        const int ij = nn / p.Cs, cc = nn - ij * p.Cs;
+        const int si = ij / p.r, sj = ij - si * p.r;
+        loff[i] = (si * (p.W * p.r) + row * p.r + sj) * p.Cs + cc;
+      } else {
+        loff[i] = row * p.ldy + n0 + c * 8;
+      }
+    } else {
+      const int hr = row - TD_YROWS;
+      const int rr = hr / HALO, px = hr - rr * HALO;
+      lrp[i] = (rr << 8) | px;
+      loff[i] = ((rr - 1) * p.W + (px - 1)) * p.ldx + k0 + c * 8;
+    }
+  }
+  auto issue = [&](int ch) {
+    const int m0 = ch * CT;
+    const int b = m0 / hw, rem = m0 - b * hw;
+    const int y = rem / p.W, x0 = rem - y * p.W;
+    const bf16_t* ybase = SHUF ? p.Y + (((long long)(b * p.H * p.r + y * p.r)) * (p.W * p.r) + (long long)x0 * p.r) * p.Cs
+                               : p.Y + (long long)m0 * p.ldy;
+    const bf16_t* xbase = p.X + (long long)m0 * p.ldx;
+    const unsigned dst = ring_base + (unsigned)(((ch - c_begin) % TD_RING) * TD_STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < TD_NI; ++i) {
+      if (i * 64 + lane < TD_PPW) {
+        const bf16_t* src;
+        if (lrp[i] < 0) {
+          src = ybase + loff[i];
+        } else {
+          const int yy = y + (lrp[i] >> 8) - 1, xx = x0 + (lrp[i] & 255) - 1;
+          src = ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) ? xbase + loff[i] : zero;
+        }
+        srk_glds16(src, __builtin_amdgcn_readfirstlane(dst + (wave * TD_PPW + i * 64) * 16));
+      }
+    }
+  };
+
+  f32x4_t acc[4][9], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[i][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.db != nullptr && tk == 0 && wave == 0;
+  const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  const int nrun = c_end - c_begin;
+  for (int s = 0; s < TD_RING - 1 && s < nrun; ++s) issue(c_begin + s);
+  for (int it = 0; it < nrun; ++it) {
+    // run `it` has landed once at most the (TD_RING - 2) runs issued after it are outstanding
+    if (it + TD_RING - 2 < nrun) srk_wait_vmcnt<TD_NI*(TD_RING - 2)>(); else srk_wait_vmcnt<0>();
+    srk_lds_barrier();
+    if (it + TD_RING - 1 < nrun) issue(c_begin + it + TD_RING - 1);
+    const bf16_t* ys = reinterpret_cast<const bf16_t*>(smem + (it % TD_RING) * TD_STAGE_BYTES);
+    const bf16_t* xs = ys + TD_YROWS * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4_t lo = lds_tr_read(tr_addr_swz64(ys, 32 * ks + 4 * g, 16 * i, lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr_swz64(ys, 32 * ks + 16 + 4 * g, 16 * i, lane));
+        yf[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int cg = 9 * wave + q;
+        const int tap = cg >> 2;
+        const int xb = (tap / 3) * HALO + (tap % 3);
+        // NOTE the swizzle is a function of the row inside the STAGE image (dY rows first), so the halo rows are offset
+        const bf16x4_t lo = lds_tr_read(tr_addr_swz64(ys, TD_YROWS + xb + 32 * ks + 4 * g, 16 * (cg & 3), lane));
+        const bf16x4_t hi = lds_tr_read(tr_addr_swz64(ys, TD_YROWS + xb + 32 * ks + 16 + 4 * g, 16 * (cg & 3), lane));
+        const bf16x8_t xf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf, acc[i][q], 0, 0, 0);
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+    (void)xs;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + 16 * i + 4 * g;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int cg = 9 * wave + q;
+      const long long col = (long long)(cg >> 2) * p.K + k0 + 16 * (cg & 3) + r16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, acc[i][q][e]);
+    }
+    if (do_bias && r16 == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.db + n + e, accb[i][e]);
+    }
+  }
+}
+
+int g_taps_dma = 1;
+
+template <bool SHUF>
+int launch_taps_dma(const WgradParams& p, hipStream_t stream) {
+  constexpr int lds = TD_RING * TD_STAGE_BYTES;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_dma_kernel<SHUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess) {
+      srk_set_error("conv wgrad (dma): cannot reserve %d bytes of LDS", lds);
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  const int tiles = (p.N / 64) * (p.K / 64);
+  const int nchunks = p.M / CT;
+  int splits = 256 / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > nchunks) splits = nchunks;
+  const int chunks_per = cdiv(nchunks, splits);
+  splits = cdiv(nchunks, chunks_per);
+  srk_probe_pre(FAM_WGRAD_CONV, stream, p.flops, p.bytes);
+  hipLaunchKernelGGL((conv_wgrad_taps_dma_kernel<SHUF>), dim3(tiles * splits), dim3(256), lds, stream, p, tiles, chunks_per);
+  srk_probe_post(FAM_WGRAD_CONV, stream);
+  return srk_check_launch("conv wgrad (all taps, dma)");
+}
+
 // ---- image-head variant: Cout <= 16, dY in fp32 ------------------------------------------------------------------
 // Weight gradient of the convs that produce the image (conv_last 64 -> 3 at HR resolution, UpsampleOneStep): same
 // all-taps structure with ONE 16-row n-fragment.  dY arrives as fp32 [pixels][COP] (the L1-loss gradient) and is split
@@ -426,17 +610,20 @@ __global__ __launch_bounds__(256) void imghead_dgrad_mfma_kernel(const float* __
 
 }  // namespace
 
-void srk_conv_wgrad_taps_enable(int on) { g_taps_enabled = on ? 1 : 0; }
+void srk_conv_wgrad_taps_enable(int on) {
+  g_taps_enabled = on ? 1 : 0;    // 0: per-tap tiles / VALU image head; 1: all-taps register-staged; 2: all-taps LDS-DMA ring (default)
+  g_taps_dma = on >= 2 ? 1 : 0;
+}
 
 // SRK_WGRAD_NOT_COVERED when the all-taps kernel does not apply (the caller then uses the per-tap tiles of wgrad.hip)
 int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream) {
   if (!g_taps_enabled || !p.conv || p.W % CT != 0 || p.N % 64 != 0 || p.K % 64 != 0 || p.ldx % 8 != 0) return SRK_WGRAD_NOT_COVERED;
   if (p.r > 1) {
     if (p.Cs % 8 != 0 || p.N != p.r * p.r * p.Cs) return SRK_WGRAD_NOT_COVERED;
-    return launch_taps<true>(p, stream);
+    return g_taps_dma ? launch_taps_dma<true>(p, stream) : launch_taps<true>(p, stream);
   }
   if (p.ldy % 8 != 0) return SRK_WGRAD_NOT_COVERED;
-  return launch_taps<false>(p, stream);
+  return g_taps_dma ? launch_taps_dma<false>(p, stream) : launch_taps<false>(p, stream);
 }
 
 // image-head convs (Cout <= 16, fp32 dY): SRK_WGRAD_NOT_COVERED -> the VALU kernel of misc.hip
