@@ -220,25 +220,29 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
   const int nchunk = (m_end - m_begin) / 64;
   if (nchunk <= 0) return;
 
-  // this wave's quarter of a stage image: 384 16-byte pieces of Y and of X (6 + 6 DMA instructions)
+  // this wave's quarter of a stage image: 384 16-byte pieces of Y and of X (6 + 6 DMA instructions).  Which piece a
+  // lane moves in instruction i never changes: its element offset relative to the chunk's first row is computed once
+  // (with one wave per SIMD the per-chunk address arithmetic otherwise competes with the MFMAs for issue slots).
+  int yoff[6], xoff[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = wave * 384 + i * 64 + lane;
+    const int row = q / 24, pos = q - row * 24;
+    const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
+    yoff[i] = row * p.ldy + n0 + c * 8;
+    xoff[i] = row * p.ldx + k0 + c * 8;
+  }
   auto issue = [&](int ch) {
     const int m0 = m_begin + ch * 64;
+    const bf16_t* yb = p.Y + (long long)m0 * p.ldy;
+    const bf16_t* xb = p.X + (long long)m0 * p.ldx;
     const unsigned dst = ring_base + (unsigned)((ch % WS_RING) * WS_STAGE_ELEMS * 2);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int q = wave * 384 + i * 64 + lane;
-      const int row = q / 24, pos = q - row * 24;
-      const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
-      srk_glds16(p.Y + (long long)(m0 + row) * p.ldy + n0 + c * 8, __builtin_amdgcn_readfirstlane(dst + (wave * 384 + i * 64) * 16));
-    }
+    for (int i = 0; i < 6; ++i)
+      srk_glds16(yb + yoff[i], __builtin_amdgcn_readfirstlane(dst + (wave * 384 + i * 64) * 16));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int q = wave * 384 + i * 64 + lane;
-      const int row = q / 24, pos = q - row * 24;
-      const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
-      srk_glds16(p.X + (long long)(m0 + row) * p.ldx + k0 + c * 8,
-                 __builtin_amdgcn_readfirstlane(dst + 64 * 192 * 2 + (wave * 384 + i * 64) * 16));
-    }
+    for (int i = 0; i < 6; ++i)
+      srk_glds16(xb + xoff[i], __builtin_amdgcn_readfirstlane(dst + 64 * 192 * 2 + (wave * 384 + i * 64) * 16));
   };
 
   f32x4_t acc[6][6], accb[6];
