@@ -357,13 +357,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
           aq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_nat(Ks, TS, 32 * ss, 16 * dt, lane), dr, aq[dt], 0, 0, 0);
         }
       }
-      bf16_t* row = dqkv + (b_ * 64 + 16 * wave + r16) * ldq + h * 32 + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        *reinterpret_cast<uint2*>(row + 16 * dt) = pack_bf4(aq[dt][0] * scale, aq[dt][1] * scale, aq[dt][2] * scale, aq[dt][3] * scale);
-        *reinterpret_cast<uint2*>(row + CA + 16 * dt) = pack_bf4(ak[dt][0], ak[dt][1], ak[dt][2], ak[dt][3]);
-        *reinterpret_cast<uint2*>(row + 2 * CA + 16 * dt) = pack_bf4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
-      }
+      // The MFMA layout gives a lane d = 4g .. 4g+3 (dt = 0) and 16 + 4g .. (dt = 1) of row r16: stored directly that is
+      // two 8-byte stores per lane and 32-byte runs per row.  v_permlane16_swap exchanges the dt = 0 quad of the odd
+      // 16-lane rows with the dt = 1 quad of the even ones, after which every lane owns 8 consecutive d (16 bytes): one
+      // store per q / k / v, 64-byte runs per row.
+      const int col = ((g & 1) << 4) | ((g >> 1) << 3);
+      bf16_t* row = dqkv + (b_ * 64 + 16 * wave + r16) * ldq + h * 32 + col;
+      auto store8 = [&](bf16_t* dst, uint2 x, uint2 y) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      };
+      store8(row, pack_bf4(aq[0][0] * scale, aq[0][1] * scale, aq[0][2] * scale, aq[0][3] * scale),
+             pack_bf4(aq[1][0] * scale, aq[1][1] * scale, aq[1][2] * scale, aq[1][3] * scale));
+      store8(row + CA, pack_bf4(ak[0][0], ak[0][1], ak[0][2], ak[0][3]), pack_bf4(ak[1][0], ak[1][1], ak[1][2], ak[1][3]));
+      store8(row + 2 * CA, pack_bf4(av[0][0], av[0][1], av[0][2], av[0][3]), pack_bf4(av[1][0], av[1][1], av[1][2], av[1][3]));
     }
     __syncthreads();
   }
