@@ -220,9 +220,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_acc(Vs, TS, 32 * ss, 16 * dt, lane), pf, o[dt], 0, 0, 0);
     }
     // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]
-    bf16_t* dst = ao + (b_ * 64 + 16 * it + r16) * CA + h * 32 + 4 * g;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<uint2*>(dst + 16 * dt) = pack_bf4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    // exchange the dt = 0 quad of the odd 16-lane rows with the dt = 1 quad of the even ones (v_permlane16_swap): every lane
+    // then owns 8 consecutive d -> one 16-byte store, 64-byte runs per row (see the backward kernel)
+    {
+      const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+      bf16_t* dst = ao + (b_ * 64 + 16 * it + r16) * CA + h * 32 + (((g & 1) << 4) | ((g >> 1) << 3));
+      *reinterpret_cast<uint4*>(dst) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
     __syncthreads();
   }
 }
