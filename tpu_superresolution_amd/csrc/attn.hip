@@ -396,8 +396,18 @@ __global__ __launch_bounds__(256) void rpb_reduce_kernel(const float* __restrict
                                                          int nslab, int nH) {
   __shared__ float part[4][64];
   const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int sidx = wave; sidx < nslab; sidx += 4) acc += slab[(((long long)sidx * nH + h) * 64 + i) * 64 + lane];
+  // eight independent loads in flight per wave: one dependent load per iteration made this kernel a chain of ~32 memory
+  // round trips (15 us for 12 MB)
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long long sstride = (long long)nH * 4096;
+  const float* base = slab + ((long long)h * 64 + i) * 64 + lane;
+  int sidx = wave;
+  for (; sidx + 28 < nslab; sidx += 32) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += base[(sidx + 4 * u) * sstride];
+  }
+  for (; sidx < nslab; sidx += 4) a8[0] += base[sidx * sstride];
+  const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   part[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
