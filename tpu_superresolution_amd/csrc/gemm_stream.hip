@@ -9,16 +9,24 @@
 // 192-column slice of W:
 //
 //   * the W slice lives in REGISTERS as MFMA fragments for the whole kernel (no per-tile W traffic at all);
-//   * waves 4-7 are LOADERS: every global read of the loop -- the A rows AND the epilogue's row operands (fp32
-//     residual rows, LayerNorm input + gradient-stream rows, bf16 pre-activations, per-row statistics) -- is an
-//     LDS-DMA (global_load_lds) into an R-deep ring of LDS slots, issued R-1 tiles ahead of its use and retired
-//     with a counted s_waitcnt vmcnt, so that >= 64 KB per CU is in flight at all times without costing VGPRs;
-//     their vmcnt counter sees only those DMAs (they never store), which makes the counted wait exact;
-//   * waves 0-3 are CONSUMERS: MFMA on the A slot (fragments read straight from the swizzled DMA image), the
-//     accumulators go through an LDS tile T and are re-read ROW-major (16 lanes per row, the layout of
-//     gemm_rowep.h) together with the row operands of the slot, then stored -- they never wait on vmcnt;
-//     with KS2 the loader waves also run the MFMA of the upper K half and add it into T (K = 576 / register cap);
-//   * two raw s_barriers per tile (three with KS2); LDS visibility by s_waitcnt lgkmcnt(0) before each barrier.
+//   * every global read of the loop -- the A rows AND the epilogue's row operands (fp32 residual rows, LayerNorm
+//     input + gradient-stream rows, bf16 pre-activations, per-row statistics) -- is an LDS-DMA (global_load_lds) into
+//     an R-deep ring of LDS slots, issued by waves 4-7 R-1 (R-2) tiles ahead of its use and retired with a counted
+//     s_waitcnt vmcnt, so that >= 64 KB per CU is in flight at all times without costing VGPRs; those waves never
+//     store, so their vmcnt counter sees only DMAs and the counted wait is exact (CDNA4 counts stores on vmcnt too);
+//   * the accumulators go through an LDS tile T and are re-read ROW-major (16 lanes per row, the layout of
+//     gemm_rowep.h) together with the row operands of the slot by waves 0-3, which only read LDS and store -- they
+//     never wait on vmcnt; raw s_barrier with s_waitcnt lgkmcnt(0) (a __syncthreads would drain the DMAs).
+//
+// Two kernels share the loader and the epilogue:
+//   gemm_stream_split_kernel  role split: waves 4-7 (front) = DMA + MFMA of tile i into T[i & 1], waves 0-3 (back) = row
+//                             epilogue of tile i-1 from T[(i-1) & 1]; ONE barrier per tile, the MFMA pipe and the
+//                             epilogue's VALU / LDS / store work overlap on every SIMD.  Default for K <= 384.
+//   gemm_stream_kernel        symmetric: waves 0-3 run MFMA + epilogue, waves 4-7 load (two barriers per tile); with KS2
+//                             both groups run half of K and the loaders add their half into T (three barriers).  Used
+//                             where the split variant does not fit: K = 576 (216 VGPRs of W per wave) and the
+//                             LayerNorm-backward epilogues (two fp32 row operands per tile leave no LDS for a second T).
+// Per-(epilogue, K) choices and tile heights were measured with tools/stream_sweep.py (srk_set_option overrides).
 //
 // The A slot image is [BM][K] bf16 row-major with the 16-byte chunk index XOR-swizzled by (row & 7).  An LDS-DMA
 // writes lane-linear (wave-uniform base + 16 * lane), so the swizzle is applied on the per-lane SOURCE address.
@@ -34,13 +42,7 @@ constexpr int SBNP = SBN + 4;    // T row pitch in floats (conflict-free float4 
 constexpr int NC = SBN / 64;     // float4 per lane per row in the row-major phase
 constexpr int LDS_BUDGET = 160 * 1024;
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) { srk_glds16(gsrc, lds_dst); }
 __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -50,10 +52,10 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  srk_wait_vmcnt<N>();
 }
 // LDS operations of this wave complete, then the workgroup barrier (no vmcnt drain: DMAs and stores stay in flight)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() { srk_lds_barrier(); }
 
 template <int EP, int KC, int BM>
 struct StreamCfg {
