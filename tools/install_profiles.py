@@ -1,0 +1,52 @@
+"""Copy the artefacts of tools/_measure.sh (gpurun_out/m_*) into profiles/ as the round's final evidence."""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write", "gemm_stream",
+                       f"{P}/{tag}_pmc_linear_gemm_stream_traffic.json"], stdout=subprocess.DEVNULL)
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write",
+                       "wgrad|attn|taps|gemm_kernel<1|imghead|smallconv", f"{P}/{tag}_pmc_other_kernels_traffic.json"], stdout=subprocess.DEVNULL)
+stats = glob.glob(f"{G}/m_prof/*/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"{P}/{tag}_final_bench_default_kernel_stats.csv")
+shutil.copy(f"{G}/m_bench.json", f"{P}/{tag}_final_bench_line.json")
+shutil.copy(f"{G}/m_prof_bench.json", f"{P}/{tag}_final_bench_line_under_rocprof.json")
+body = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), f"{G}/m_prof", "25"], text=True)
+tot, n = 0.0, 0
+for r in csv.DictReader(open(stats)):
+    if "gemm_stream" in r["Name"]:
+        tot += float(r["TotalDurationNs"])
+        n += int(r["Calls"])
+d = json.load(open(f"{G}/m_bench.json"))
+hdr = f"""# rocprofv3 --kernel-trace --stats of the default bench command (round 1, final)
+
+Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` (25 train steps of cfg3,
+bs 32, incl. 5 warm-up; the HIP-event probe brackets every 7th launch of the roofline family during the 20 timed steps).
+Bench line of the same run: `{tag}_final_bench_line_under_rocprof.json`; un-profiled bench line: `{tag}_final_bench_line.json`
+({d['ms_per_step']:.2f} ms/step = {d['value'] / 1e6:.1f} M HR px/s).
+
+"""
+tail = f"""
+
+Template arguments: `gemm_stream_split_kernel<epilogue, K/64, rows per tile, epilogue waves>`, `gemm_stream_kernel<epilogue, K/64, rows per
+tile, K split>`; `gemm_kernel<loader, epilogue, NT, narrow>` (loader 1 conv3x3 / 2 conv3x3 over pixel-shuffled input);
+epilogue 0 bf16, 1 qkv, 2 proj+residual+LN2, 3 GELU, 4 residual+next LN, 5 dGELU, 6 LeakyReLU, 7 PixelShuffle, 8 image,
+10 residual->bf16, 11 dLeakyReLU, 12 f32+bf16, 13 fused LayerNorm backward.
+
+The roofline kernel family of bench.py is `gemm_stream*_kernel` (csrc/gemm_stream.hip): 288 launches/step, average duration in
+this trace {tot / n / 1e3:.1f} us over {n} launches; bench.py's HIP-event probe in the un-profiled run: {d['roofline']['avg_launch_us']:.1f} us
+(`roofline.avg_launch_us`, every 7th launch sampled; the event pair itself adds ~3 us to a bracketed launch).
+PMC HBM traffic of the family: `{tag}_pmc_linear_gemm_stream_traffic.json` (304 MB/launch measured vs 283 MB algorithmic un-padded).
+"""
+open(f"{P}/{tag}_final_bench_default_kernel_stats.md", "w").write(hdr + body + tail)
+r = d["roofline"]
+print(f"ms/step {d['ms_per_step']:.2f}  value {d['value'] / 1e6:.2f} M px/s  tflops {d['config']['step_tflops_per_gpu']:.1f}  roofline {r['achieved']:.0f} GB/s "
+      f"frac {r['frac']:.3f}  probe {r['avg_launch_us']:.1f} us  rocprof {tot / n / 1e3:.1f} us  share {r['share_of_step']:.3f}  cpu {d['cpu_baseline']['value']:.0f}")
