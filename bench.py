@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HR_PX_PER_SAMPLE = 256 * 256
 FLOP_PER_IMAGE_TRAIN = 321.299e9      # fwd+bwd algorithmic FLOPs per 64x64 LR image
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
-PROBE_STRIDE = 7
+PROBE_STRIDE = 5
 HBM_PEAK_GBS = 8000.0                # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy ceiling)
 
 
@@ -116,9 +116,9 @@ def main():
     probe = (not args.no_roofline) and rank == 0
     lib = _lib.lib()
     if probe:
-        # family 1 = linear-layer GEMMs (8 launches per Swin block).  Every 7th launch is bracketed by HIP events on the
-        # launch stream: 7 is coprime with the 8-launch block pattern, so the sample is uniform over the eight kernels;
-        # bracketing all 288 launches per step costs ~4 % of the step in event records.
+        # family 1 = linear-layer GEMMs (7 launches per Swin block; 8 where the fused qkv+attention kernel does not apply).
+        # Every 5th launch is bracketed by HIP events on the launch stream: 5 is coprime with both block patterns, so the
+        # sample is uniform over the kernels; bracketing every launch costs ~4 % of the step in event records.
         _lib.check(lib.srk_set_option(b"probe_stride", PROBE_STRIDE))
         _lib.check(lib.srk_probe_begin(1, 400 * args.steps))
     t0 = time.perf_counter()

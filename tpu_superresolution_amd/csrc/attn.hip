@@ -51,14 +51,8 @@ __device__ __forceinline__ bf16x8_t row_frag(const bf16_t* tile, int stride, int
   return *reinterpret_cast<const bf16x8_t*>(tile + row * stride + k0);
 }
 
-__device__ __forceinline__ float xmax4(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float xsum4(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-}
+__device__ __forceinline__ float xmax4(float v) { return xrow_max4(v); }
+__device__ __forceinline__ float xsum4(float v) { return xrow_sum4(v); }
 
 // scores^T + bias + mask -> probabilities^T (in place), T-layout: s[jt][it][e] = S[i=16it+r16][j=16jt+4g+e]
 struct BiasRegs {   // dense bias of one head held in 64 VGPRs (forward: reused across the windows of a wave)

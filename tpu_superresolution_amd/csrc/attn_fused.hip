@@ -1,0 +1,290 @@
+// Fused QKV projection + window attention forward for the classical SwinIR width (C = 180 -> 192, 6 heads x 32):
+//
+//   qkv = xn1_window . Wqkv^T + b  (q scaled)        network_swinir.py:121-124
+//   ao  = softmax(q k^T + bias + mask) v              network_swinir.py:125-142
+//
+// Run separately, the projection writes q/k/v (150 MB per launch at cfg3) and the attention kernel reads them right
+// back (another 150 MB); both kernels sit on the HBM roofline.  A window is 64 consecutive rows of the window-ordered
+// LayerNorm output, so one workgroup can take a window from xn1 to ao with q/k/v living only in LDS; q/k/v are still
+// written out once for the backward pass, but never re-read in forward (-150 MB per block, -1 launch).
+//
+// One persistent 512-thread workgroup per CU walks the windows b_ = blockIdx.x, + gridDim.x, ...:
+//   waves 0-5  MFMA waves.  Wave w owns output columns [96 w, 96 w + 96) of the projection (which = w / 2, three heads)
+//              with its W slice in registers (36 fragments, 144 VGPRs); after the window's q/k/v head tiles are in LDS,
+//              wave w runs the attention of head w (four 16-query tiles: 4 + 4 MFMAs each, softmax in registers, as
+//              attn.hip).  Their rel-pos-bias loads are issued a whole projection ahead of their use, so the
+//              in-order vmcnt counter never makes them wait for the (older) stores.
+//              After its attention a wave stores the q/k/v tiles of its head (1 KB contiguous per instruction) and, after the
+//              next barrier, its share of the window's ao tile -- all from LDS.
+//   wave  6    spare (barriers only).
+//   wave  7    loader: the window's 64 x 192 bf16 rows arrive by LDS-DMA (swizzled on the source address) into a 2-slot
+//              ring, one window ahead; it never stores, so vmcnt(0) is an exact "my DMAs have landed".
+// Three raw barriers per window.  The ao tile aliases the ring slot that the window's GEMM has just consumed.
+#include "kernels.h"
+
+namespace {
+
+constexpr int FT = 40;                 // LDS row stride (elements) of a [64][32] bf16 head tile (as attn.hip TS)
+constexpr int F_K = 192, F_CA = 192, F_NH = 6;
+constexpr int F_SLOT = 64 * F_K * 2;   // 24576 B: one window of xn1 / the ao tile
+constexpr int F_TILE = 64 * FT;        // elements per head tile
+constexpr int F_LDS = 2 * F_SLOT + 18 * F_TILE * 2 + 3 * F_CA * 4;    // ring + head tiles + projection bias (fp32)
+
+struct FusedParams {
+  const bf16_t* xn;     // [B_*64][lda] window-order rows
+  int lda;
+  const bf16_t* Wt;     // [576][192] packed qkv weight (q rows first)
+  const float* bias;    // [576] or null
+  float scale;
+  bf16_t* qkv;          // [3][B_][6][64][32]
+  const float* biasd;   // [6][64][64] dense relative-position bias
+  bf16_t* ao;           // [B_*64][192]
+  long long B_;
+  WinGeom geom;
+};
+
+__device__ __forceinline__ bf16x8_t f_cat4(bf16x4_t lo, bf16x4_t hi) {
+  return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ float f_xmax4(float v) { return xrow_max4(v); }
+__device__ __forceinline__ float f_xsum4(float v) { return xrow_sum4(v); }
+
+__global__ __launch_bounds__(512) void qkv_attn_fwd_kernel(const FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + 2 * F_SLOT);       // [which][head][64][FT]
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const long long nwin = (p.B_ - blockIdx.x + gridDim.x - 1) / gridDim.x;     // windows of this workgroup
+  if (nwin <= 0) return;
+  // projection bias -> LDS once: the MFMA waves have no registers left for it, and re-reading it from L2 per 16-row
+  // quarter put an exposed ~1 us round trip into every quarter (measured: 38 of 102 us)
+  float* pbias = reinterpret_cast<float*>(smem + 2 * F_SLOT + 18 * F_TILE * 2);
+  for (int i = tid; i < 3 * F_CA; i += 512) pbias[i] = p.bias ? p.bias[i] : 0.f;
+  // (visible to the MFMA waves after the first barrier of the window loop)
+
+  if (wave == 7) {
+    // ================================== loader ===================================================
+    int off[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      const int q = i * 64 + lane;
+      const int row = q / 24, pos = q - row * 24;
+      off[i] = row * p.lda + ((pos ^ (row & 7)) << 3);
+    }
+    auto issue = [&](long long t) {
+      const bf16_t* base = p.xn + (blockIdx.x + t * gridDim.x) * 64 * (long long)p.lda;
+      const unsigned dst = smem_base + (unsigned)((t & 1) * F_SLOT);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) srk_glds16(base + off[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
+    };
+    issue(0);
+    for (long long t = 0; t < nwin; ++t) {
+      srk_wait_vmcnt<0>();
+      srk_lds_barrier();                        // Ba: window t is in its slot
+      if (t + 1 < nwin) issue(t + 1);           // into slot (t+1)&1: the ao tile it held (window t-1) was stored before Ba(t)
+      srk_lds_barrier();                        // Bb
+      srk_lds_barrier();                        // Bc
+    }
+  } else if (wave == 6) {
+    // ================================== spare wave (barriers only) ===============================
+    for (long long t = 0; t < nwin; ++t) {
+      srk_lds_barrier();
+      srk_lds_barrier();
+      srk_lds_barrier();
+    }
+  } else {
+    // ================================== MFMA waves 0..5 ==========================================
+    const int which = wave >> 1, hb = 3 * (wave & 1);          // projection: q/k/v selector and first head of this wave
+    bf16x8_t wf[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int s = 0; s < 6; ++s)
+        wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(96 * wave + 16 * j + r16) * F_K + s * 32 + g * 8);
+    const float* bqp = pbias + 96 * wave + 4 * g;
+    const float sc = which == 0 ? p.scale : 1.0f;
+    const int h = wave;                                          // attention: this wave's head
+    const float* bias_h = p.biasd + h * 4096;
+    const bf16_t* Qs = tiles + (0 * F_NH + h) * F_TILE;
+    const bf16_t* Ks = tiles + (1 * F_NH + h) * F_TILE;
+    const bf16_t* Vs = tiles + (2 * F_NH + h) * F_TILE;
+
+    for (long long t = 0; t < nwin; ++t) {
+      const long long b_ = blockIdx.x + t * gridDim.x;
+      const unsigned char* As = smem + (t & 1) * F_SLOT;
+      // rel-pos bias of the first query tile: issued now, consumed after the projection (an L2 round trip costs more than a
+      // whole attention unit when it is waited for in place)
+      f32x4_t bnext[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias_h + r16 * 64 + 16 * jt + 4 * g);
+        bnext[jt] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+      }
+      srk_lds_barrier();                        // Ba: xn1 rows of window t are in LDS; head tiles are free
+      // ---- projection: 64 rows x 96 columns in four 16-row quarters (24 accumulator registers at a time) ----------------
+#pragma unroll 1
+      for (int mq = 0; mq < 4; ++mq) {
+        f32x4_t acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int row = 16 * mq + r16;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(As + row * (F_K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+        }
+        // acc[j][e] = column 96 wave + 16 j + 4 g + e of row 16 mq + r16 -> head tile [token][d]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int hh = hb + (j >> 1), d = 16 * (j & 1) + 4 * g;
+          bf16_t* tp = tiles + (which * F_NH + hh) * F_TILE + row * FT + d;
+          const float4 bq = *reinterpret_cast<const float4*>(bqp + 16 * j);
+          *reinterpret_cast<uint2*>(tp) = pack_bf4((acc[j][0] + bq.x) * sc, (acc[j][1] + bq.y) * sc, (acc[j][2] + bq.z) * sc,
+                                                   (acc[j][3] + bq.w) * sc);
+        }
+      }
+      srk_lds_barrier();                        // Bb: all q/k/v head tiles of the window are complete
+      // ---- attention of head `wave`: four 16-query tiles (attn.hip attn_fwd_kernel, one wave per tile there) ----------
+      {
+        const int w = (int)(b_ % p.geom.nW);
+        const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
+        const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
+        unsigned char* aot = smem + (t & 1) * F_SLOT;            // the consumed xn1 slot becomes the ao tile [64][192]
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * FT + 8 * g);
+          f32x4_t s[4];
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+            s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * FT + 8 * g), qf,
+                                                          f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) s[jt] += bnext[jt];
+          if (it < 3) {                          // next tile's bias: in flight under this tile's softmax and P.V
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+              const float4 bv = *reinterpret_cast<const float4*>(bias_h + (16 * (it + 1) + r16) * 64 + 16 * jt + 4 * g);
+              bnext[jt] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+            }
+          }
+          if (masked) {
+            const int labi = win_region_label(p.geom, w, 16 * it + r16);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
+          }
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
+          mx = f_xmax4(mx);
+          float sum = 0.f;
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s[jt][e] = __expf(s[jt][e] - mx);
+              sum += s[jt][e];
+            }
+          const float inv = 1.0f / f_xsum4(sum);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[jt][e] *= inv;
+          f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const uint2 lo = pack_bf4(s[2 * ss][0], s[2 * ss][1], s[2 * ss][2], s[2 * ss][3]);
+            const uint2 hi = pack_bf4(s[2 * ss + 1][0], s[2 * ss + 1][1], s[2 * ss + 1][2], s[2 * ss + 1][3]);
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const bf16x8_t vf = f_cat4(lds_tr_read(tr_addr(Vs, FT, 32 * ss + 4 * g, 16 * dt, lane)),
+                                         lds_tr_read(tr_addr(Vs, FT, 32 * ss + 16 + 4 * g, 16 * dt, lane)));
+              o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+          }
+          // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]: 8 consecutive d per lane after the 16-lane-row swap
+          const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+          *reinterpret_cast<uint4*>(aot + ((16 * it + r16) * F_CA + h * 32 + (((g & 1) << 4) | ((g >> 1) << 3))) * 2) =
+              make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+      // ---- q / k / v of this wave's head -> global, for the backward pass (1 KB contiguous per instruction).  The stores
+      // queue behind nothing this wave waits for soon: its next loads (the bias prefetch of the next window) are consumed
+      // only after that window's projection, microseconds later.
+#pragma unroll 1
+      for (int wh = 0; wh < 3; ++wh) {
+        const bf16_t* src = tiles + (wh * F_NH + h) * F_TILE;
+        bf16_t* dst = p.qkv + ((wh * p.B_ + b_) * F_NH + h) * 2048;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 16 + (lane >> 2), ch = lane & 3;
+          *reinterpret_cast<uint4*>(dst + row * 32 + ch * 8) = *reinterpret_cast<const uint4*>(src + row * FT + ch * 8);
+        }
+      }
+      srk_lds_barrier();                        // Bc: the ao tile is complete; head tiles are no longer read
+      {                                         // the window's 24 KB of ao: 24 x 1 KB, four per MFMA wave
+        const unsigned char* aot = smem + (t & 1) * F_SLOT;
+        bf16_t* adst = p.ao + b_ * 64 * F_CA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = (wave * 4 + i) * 64 + lane;
+          *reinterpret_cast<uint4*>(adst + idx * 8) = *reinterpret_cast<const uint4*>(aot + idx * 16);
+        }
+      }
+    }
+  }
+}
+
+int g_attn_fused = 1;
+int g_fused_cus = 0;
+
+}  // namespace
+
+void srk_attn_fused_enable(int on) { g_attn_fused = on ? 1 : 0; }
+
+// SRK_NOT_COVERED (1) when the fused kernel does not apply: the caller then runs the projection GEMM and srk_launch_attn_fwd.
+int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const float* bias, float scale, bf16_t* qkv,
+                            const float* biasd, bf16_t* ao, long long B_, int nH, int CA, int K, WinGeom geom, hipStream_t stream) {
+  if (!g_attn_fused || nH != F_NH || CA != F_CA || K != F_K || lda % 8 != 0) return SRK_NOT_COVERED;
+  if (g_fused_cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    g_fused_cus = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_fused_cus = prop.multiProcessorCount;
+  }
+  if (g_fused_cus < 1 || B_ < g_fused_cus) return SRK_NOT_COVERED;      // fewer windows than CUs: the W preload does not amortise
+  static int configured = 0;
+  if (!configured) {
+    const void* fn = reinterpret_cast<const void*>(&qkv_attn_fwd_kernel);
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, fn) != hipSuccess) {
+      srk_set_error("qkv+attention: cannot query the kernel");
+      return SRK_E_LAUNCH;
+    }
+    if (attr.localSizeBytes > 0) {
+      configured = -1;              // spills would put scratch traffic on the loader's vmcnt counter
+    } else {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) != hipSuccess) {
+        srk_set_error("qkv+attention: cannot reserve %d bytes of LDS", F_LDS);
+        return SRK_E_LAUNCH;
+      }
+      configured = 1;
+    }
+  }
+  if (configured < 0) return SRK_NOT_COVERED;
+  FusedParams fp;
+  fp.xn = xn; fp.lda = lda; fp.Wt = Wt; fp.bias = bias; fp.scale = scale; fp.qkv = qkv; fp.biasd = biasd; fp.ao = ao; fp.B_ = B_;
+  fp.geom = geom;
+  hipLaunchKernelGGL(qkv_attn_fwd_kernel, dim3(g_fused_cus), dim3(512), F_LDS, stream, fp);
+  return srk_check_launch("qkv+attention");
+}

@@ -182,6 +182,23 @@ __device__ __forceinline__ float wave_sum16(float v) {
   return v;
 }
 
+// max / sum over lanes l, l^16, l^32, l^48 (the four 16-lane rows of a wave) without an LDS round trip: v_permlane16_swap
+// exchanges the odd rows of its first operand with the even rows of the second, v_permlane32_swap the upper and lower
+// halves; with both operands = v, {result0, result1} is {v, partner} or {partner, v} on every lane, so a commutative op of
+// the two is the butterfly step.  (__shfl_xor with 16 / 32 compiles to ds_bpermute: two dependent LDS round trips.)
+__device__ __forceinline__ float xrow_max4(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xrow_sum4(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ float wave_sum64(float v) {
   v = wave_sum16(v);
   v += __shfl_xor(v, 16, 64);

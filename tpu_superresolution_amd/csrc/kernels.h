@@ -5,6 +5,10 @@
 #include "pack.h"
 #include "wgrad.h"
 
+// attn_fused.hip: projection + attention in one kernel (classical width); SRK_NOT_COVERED -> run them separately
+int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const float* bias, float scale, bf16_t* qkv, const float* biasd,
+                            bf16_t* ao, long long B_, int nH, int CA, int K, WinGeom geom, hipStream_t stream);
+void srk_attn_fused_enable(int on);
 int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long long B_, int nH, WinGeom geom, hipStream_t stream);
 int srk_attn_bwd_slabs(long long B_, int nH, int* wpw_out);
 int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,

@@ -595,16 +595,23 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
         RUN(srk_launch_ln_fwd(c.at<float>(ba.x_in), params + bw.n1w, params + bw.n1b, c.at<bf16_t>(ba.xn1w), nullptr,
                               c.at<float>(ba.mean1), c.at<float>(ba.rstd1), T, C, CP, &geom, st));
       ln1_done = false;
-      {  // qkv projection, q scaled                  :121-124
-        GemmParams g = {};
-        g.A = c.at<bf16_t>(ba.xn1w); g.lda = CP; g.Wt = c.packed + bw.Wqkv; g.M = T; g.N = 3 * bw.CA; g.K = CP;
-        g.bias = c.side + bw.bqkv; g.outb = c.at<bf16_t>(ba.qkv); g.scale = bw.scale; g.nH = bw.nH; g.CA = bw.CA; g.B_ = T / 64;
-        g.flops = fl_qkv;
-        g.bytes = (double)T * (2.0 * C + 6.0 * C) + 6.0 * C * C;                 // xn1 in, q/k/v out, weights once
-        RUN(srk_launch_gemm(LD_ROWS, EP_QKV, g, st));
+      // qkv projection (q scaled, :121-124) + softmax(qk^T + bias + mask) v (:125-142): one kernel per window where it applies
+      const int rc_fused = srk_launch_qkv_attn_fwd(c.at<bf16_t>(ba.xn1w), CP, c.packed + bw.Wqkv, c.side + bw.bqkv, bw.scale,
+                                                   c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, bw.CA, CP,
+                                                   geom, st);
+      if (rc_fused != SRK_NOT_COVERED) {
+        RUN(rc_fused);
+      } else {
+        {
+          GemmParams g = {};
+          g.A = c.at<bf16_t>(ba.xn1w); g.lda = CP; g.Wt = c.packed + bw.Wqkv; g.M = T; g.N = 3 * bw.CA; g.K = CP;
+          g.bias = c.side + bw.bqkv; g.outb = c.at<bf16_t>(ba.qkv); g.scale = bw.scale; g.nH = bw.nH; g.CA = bw.CA; g.B_ = T / 64;
+          g.flops = fl_qkv;
+          g.bytes = (double)T * (2.0 * C + 6.0 * C) + 6.0 * C * C;                 // xn1 in, q/k/v out, weights once
+          RUN(srk_launch_gemm(LD_ROWS, EP_QKV, g, st));
+        }
+        RUN(srk_launch_attn_fwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, geom, st));
       }
-      // softmax(qk^T + bias + mask) v                :125-142
-      RUN(srk_launch_attn_fwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, geom, st));
       {  // proj + window reverse + un-roll + residual :143, :265-276
         GemmParams g = {};
         g.A = c.at<bf16_t>(ba.ao); g.lda = bw.CA; g.Wt = c.packed + bw.Wproj; g.M = T; g.N = CP; g.K = bw.CA;
