@@ -140,8 +140,8 @@ def main():
             if os.path.exists(tf):
                 traffic = json.load(open(tf))["avg_hbm_bytes_per_launch"]      # rocprofv3 PMC, same workload
             roof = {"bound": "hbm", "kernel": "gemm_stream_kernel / gemm_stream_split_kernel (csrc/gemm_stream.hip: persistent LDS-DMA "
-                                               "GEMM of the linear layers -- qkv/proj/fc1/fc2 forward and dgrad with their fused "
-                                               "bias/GELU/residual/LayerNorm epilogues)",
+                                               "GEMM of the linear layers -- proj/fc1/fc2 forward and the qkv/proj/fc1/fc2 dgrads with their "
+                                               "fused bias/GELU/residual/LayerNorm epilogues; the qkv forward lives in attn_fused.hip)",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value, "sampled_every": PROBE_STRIDE,
                     "avg_launch_us": 1e3 * ms.value / n.value, "share_of_step": PROBE_STRIDE * ms.value / (1e3 * elapsed),

@@ -36,7 +36,7 @@ struct FusedParams {
   const bf16_t* Wt;     // [576][192] packed qkv weight (q rows first)
   const float* bias;    // [576] or null
   float scale;
-  bf16_t* qkv;          // [3][B_][6][64][32]
+  bf16_t* qkv;          // [3][B_][6][64][32], or null (inference: nothing reads it)
   const float* biasd;   // [6][64][64] dense relative-position bias
   bf16_t* ao;           // [B_*64][192]
   long long B_;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fwd_kernel(const FusedParams p) 
       // queue behind nothing this wave waits for soon: its next loads (the bias prefetch of the next window) are consumed
       // only after that window's projection, microseconds later.
 #pragma unroll 1
-      for (int wh = 0; wh < 3; ++wh) {
+      for (int wh = 0; wh < (p.qkv ? 3 : 0); ++wh) {        // inference: q/k/v never leave the CU
         const bf16_t* src = tiles + (wh * F_NH + h) * F_TILE;
         bf16_t* dst = p.qkv + ((wh * p.B_ + b_) * F_NH + h) * 2048;
 #pragma unroll

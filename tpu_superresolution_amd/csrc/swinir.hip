@@ -597,7 +597,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
       ln1_done = false;
       // qkv projection (q scaled, :121-124) + softmax(qk^T + bias + mask) v (:125-142): one kernel per window where it applies
       const int rc_fused = srk_launch_qkv_attn_fwd(c.at<bf16_t>(ba.xn1w), CP, c.packed + bw.Wqkv, c.side + bw.bqkv, bw.scale,
-                                                   c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, bw.CA, CP,
+                                                   w.training ? c.at<bf16_t>(ba.qkv) : nullptr, c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, bw.CA, CP,
                                                    geom, st);
       if (rc_fused != SRK_NOT_COVERED) {
         RUN(rc_fused);
