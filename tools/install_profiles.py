@@ -26,10 +26,11 @@ for r in csv.DictReader(open(stats)):
         tot += float(r["TotalDurationNs"])
         n += int(r["Calls"])
 d = json.load(open(f"{G}/m_bench.json"))
+traffic = json.load(open(f"{P}/{tag}_pmc_linear_gemm_stream_traffic.json"))["avg_hbm_bytes_per_launch"]
 hdr = f"""# rocprofv3 --kernel-trace --stats of the default bench command (round 1, final)
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` (25 train steps of cfg3,
-bs 32, incl. 5 warm-up; the HIP-event probe brackets every 7th launch of the roofline family during the 20 timed steps).
+bs 32, incl. 5 warm-up; the HIP-event probe brackets every {d['roofline'].get('sampled_every', 1)}th launch of the roofline family during the 20 timed steps).
 Bench line of the same run: `{tag}_final_bench_line_under_rocprof.json`; un-profiled bench line: `{tag}_final_bench_line.json`
 ({d['ms_per_step']:.2f} ms/step = {d['value'] / 1e6:.1f} M HR px/s).
 
@@ -41,10 +42,11 @@ tile, K split>`; `gemm_kernel<loader, epilogue, NT, narrow>` (loader 1 conv3x3 /
 epilogue 0 bf16, 1 qkv, 2 proj+residual+LN2, 3 GELU, 4 residual+next LN, 5 dGELU, 6 LeakyReLU, 7 PixelShuffle, 8 image,
 10 residual->bf16, 11 dLeakyReLU, 12 f32+bf16, 13 fused LayerNorm backward.
 
-The roofline kernel family of bench.py is `gemm_stream*_kernel` (csrc/gemm_stream.hip): 288 launches/step, average duration in
+The roofline kernel family of bench.py is `gemm_stream*_kernel` (csrc/gemm_stream.hip): {n / 25:.0f} launches/step, average duration in
 this trace {tot / n / 1e3:.1f} us over {n} launches; bench.py's HIP-event probe in the un-profiled run: {d['roofline']['avg_launch_us']:.1f} us
-(`roofline.avg_launch_us`, every 7th launch sampled; the event pair itself adds ~3 us to a bracketed launch).
-PMC HBM traffic of the family: `{tag}_pmc_linear_gemm_stream_traffic.json` (304 MB/launch measured vs 283 MB algorithmic un-padded).
+(`roofline.avg_launch_us`, every {d['roofline'].get('sampled_every', 1)}th launch sampled; the event pair itself adds ~3 us to a bracketed launch).
+PMC HBM traffic of the family: `{tag}_pmc_linear_gemm_stream_traffic.json` ({traffic / 1e6:.0f} MB/launch measured vs {d['roofline']['algorithmic_bytes_per_launch'] / 1e6:.0f} MB
+algorithmic un-padded; the difference is the 180->192 channel and 30->32 head padding).
 """
 open(f"{P}/{tag}_final_bench_default_kernel_stats.md", "w").write(hdr + body + tail)
 r = d["roofline"]
