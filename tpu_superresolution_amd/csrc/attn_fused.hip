@@ -6,20 +6,26 @@
 // Run separately, the projection writes q/k/v (150 MB per launch at cfg3) and the attention kernel reads them right
 // back (another 150 MB); both kernels sit on the HBM roofline.  A window is 64 consecutive rows of the window-ordered
 // LayerNorm output, so one workgroup can take a window from xn1 to ao with q/k/v living only in LDS; q/k/v are still
-// written out once for the backward pass, but never re-read in forward (-150 MB per block, -1 launch).
+// written out once for the backward pass, but never re-read in forward (-150 MB per block, -1 launch); in inference they
+// never leave the CU.
 //
-// One persistent 512-thread workgroup per CU walks the windows b_ = blockIdx.x, + gridDim.x, ...:
-//   waves 0-5  MFMA waves.  Wave w owns output columns [96 w, 96 w + 96) of the projection (which = w / 2, three heads)
-//              with its W slice in registers (36 fragments, 144 VGPRs); after the window's q/k/v head tiles are in LDS,
-//              wave w runs the attention of head w (four 16-query tiles: 4 + 4 MFMAs each, softmax in registers, as
-//              attn.hip).  Their rel-pos-bias loads are issued a whole projection ahead of their use, so the
-//              in-order vmcnt counter never makes them wait for the (older) stores.
-//              After its attention a wave stores the q/k/v tiles of its head (1 KB contiguous per instruction) and, after the
-//              next barrier, its share of the window's ao tile -- all from LDS.
-//   wave  6    spare (barriers only).
-//   wave  7    loader: the window's 64 x 192 bf16 rows arrive by LDS-DMA (swizzled on the source address) into a 2-slot
-//              ring, one window ahead; it never stores, so vmcnt(0) is an exact "my DMAs have landed".
-// Three raw barriers per window.  The ao tile aliases the ring slot that the window's GEMM has just consumed.
+// One persistent 512-thread workgroup per CU walks the windows b_ = blockIdx.x, + gridDim.x, ...  All eight waves run
+// the projection and the attention:
+//   projection  the 36 16-column fragments of the 576 output columns are dealt 5 / 5 / 5 / 5 / 4 / 4 / 4 / 4 to waves 0..7;
+//               waves w and w + 4 share a SIMD, so every SIMD carries nine fragments.  Each wave keeps its W slice in
+//               registers (<= 30 MFMA fragments, 120 VGPRs) and walks the 64 rows in four 16-row quarters; results
+//               (+ bias, q scale, bf16) go to per-(q/k/v, head) LDS tiles [64][40].
+//   attention   the 24 (head, 16-query tile) units of the window are dealt three per wave (4 + 4 MFMAs each, softmax in
+//               registers, as attn.hip).  The rel-pos bias of a unit is loaded one unit ahead (the first one before the
+//               projection), because an L2 round trip waited for in place costs more than the unit itself.
+//   stores      waves 0..6 write the q/k/v tiles (1 KB contiguous per instruction) and, after the last barrier, the
+//               window's 24 KB ao tile -- all from LDS.  Their next loads (the bias prefetch) are consumed microseconds
+//               later, so the in-order vmcnt counter never makes them wait for these stores.
+//   loading     wave 7 never stores: it issues the LDS-DMA of the next window's 64 x 192 bf16 rows (swizzled on the source
+//               address, 2-slot ring) right after the first barrier, and its vmcnt(0) before the next one is "landed".
+// Three raw barriers per window.  The ao tile aliases the ring slot that the window's projection has just consumed.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace {
@@ -46,203 +52,200 @@ struct FusedParams {
 __device__ __forceinline__ bf16x8_t f_cat4(bf16x4_t lo, bf16x4_t hi) {
   return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__device__ __forceinline__ float f_xmax4(float v) { return xrow_max4(v); }
-__device__ __forceinline__ float f_xsum4(float v) { return xrow_sum4(v); }
 
-__global__ __launch_bounds__(512) void qkv_attn_fwd_kernel(const FusedParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// NF: 16-column fragments of the projection owned by this wave (5 or 4); LOADER: this wave issues the DMA and never stores
+template <int NF, bool LOADER>
+__device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* smem, int wave, int lane, long long nwin) {
   bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + 2 * F_SLOT);       // [which][head][64][FT]
+  const float* pbias = reinterpret_cast<const float*>(smem + 2 * F_SLOT + 18 * F_TILE * 2);
   const unsigned smem_base = (unsigned)(size_t)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
-  const long long nwin = (p.B_ - blockIdx.x + gridDim.x - 1) / gridDim.x;     // windows of this workgroup
-  if (nwin <= 0) return;
-  // projection bias -> LDS once: the MFMA waves have no registers left for it, and re-reading it from L2 per 16-row
-  // quarter put an exposed ~1 us round trip into every quarter (measured: 38 of 102 us)
-  float* pbias = reinterpret_cast<float*>(smem + 2 * F_SLOT + 18 * F_TILE * 2);
-  for (int i = tid; i < 3 * F_CA; i += 512) pbias[i] = p.bias ? p.bias[i] : 0.f;
-  // (visible to the MFMA waves after the first barrier of the window loop)
+  const int f0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);          // first fragment of this wave
 
-  if (wave == 7) {
-    // ================================== loader ===================================================
-    int off[24];
+  bf16x8_t wf[NF][6];
+#pragma unroll
+  for (int j = 0; j < NF; ++j)
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+      wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(16 * (f0 + j) + r16) * F_K + s * 32 + g * 8);
+
+  // loader only: element offset of the 16-byte piece lane `lane` moves in DMA instruction i (constant over the windows)
+  int off[LOADER ? 24 : 1];
+  if constexpr (LOADER) {
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
       const int q = i * 64 + lane;
       const int row = q / 24, pos = q - row * 24;
       off[i] = row * p.lda + ((pos ^ (row & 7)) << 3);
     }
-    auto issue = [&](long long t) {
+  }
+  auto issue = [&](long long t) {
+    if constexpr (LOADER) {
       const bf16_t* base = p.xn + (blockIdx.x + t * gridDim.x) * 64 * (long long)p.lda;
       const unsigned dst = smem_base + (unsigned)((t & 1) * F_SLOT);
 #pragma unroll
       for (int i = 0; i < 24; ++i) srk_glds16(base + off[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
-    };
-    issue(0);
-    for (long long t = 0; t < nwin; ++t) {
-      srk_wait_vmcnt<0>();
-      srk_lds_barrier();                        // Ba: window t is in its slot
-      if (t + 1 < nwin) issue(t + 1);           // into slot (t+1)&1: the ao tile it held (window t-1) was stored before Ba(t)
-      srk_lds_barrier();                        // Bb
-      srk_lds_barrier();                        // Bc
     }
-  } else if (wave == 6) {
-    // ================================== spare wave (barriers only) ===============================
-    for (long long t = 0; t < nwin; ++t) {
-      srk_lds_barrier();
-      srk_lds_barrier();
-      srk_lds_barrier();
+  };
+  auto load_bias = [&](f32x4_t (&b)[4], int u) {      // rel-pos bias rows of unit u = 4 h + it, this lane's 16 values
+    const float* bp = p.biasd + (u >> 2) * 4096 + (16 * (u & 3) + r16) * 64 + 4 * g;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * jt);
+      b[jt] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
     }
-  } else {
-    // ================================== MFMA waves 0..5 ==========================================
-    const int which = wave >> 1, hb = 3 * (wave & 1);          // projection: q/k/v selector and first head of this wave
-    bf16x8_t wf[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-      for (int s = 0; s < 6; ++s)
-        wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(96 * wave + 16 * j + r16) * F_K + s * 32 + g * 8);
-    const float* bqp = pbias + 96 * wave + 4 * g;
-    const float sc = which == 0 ? p.scale : 1.0f;
-    const int h = wave;                                          // attention: this wave's head
-    const float* bias_h = p.biasd + h * 4096;
-    const bf16_t* Qs = tiles + (0 * F_NH + h) * F_TILE;
-    const bf16_t* Ks = tiles + (1 * F_NH + h) * F_TILE;
-    const bf16_t* Vs = tiles + (2 * F_NH + h) * F_TILE;
+  };
 
-    for (long long t = 0; t < nwin; ++t) {
-      const long long b_ = blockIdx.x + t * gridDim.x;
-      const unsigned char* As = smem + (t & 1) * F_SLOT;
-      // rel-pos bias of the first query tile: issued now, consumed after the projection (an L2 round trip costs more than a
-      // whole attention unit when it is waited for in place)
-      f32x4_t bnext[4];
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias_h + r16 * 64 + 16 * jt + 4 * g);
-        bnext[jt] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
-      }
+  if constexpr (LOADER) issue(0);
+  for (long long t = 0; t < nwin; ++t) {
+    const long long b_ = blockIdx.x + t * gridDim.x;
+    const unsigned char* As = smem + (t & 1) * F_SLOT;
+    f32x4_t bnext[4];
+    if constexpr (LOADER) {
+      srk_wait_vmcnt<0>();                      // this wave's DMAs of window t (and nothing else) have landed
+      srk_lds_barrier();                        // Ba
+      if (t + 1 < nwin) issue(t + 1);           // into slot (t+1)&1: the ao tile it held (window t-1) was stored before Ba(t)
+      load_bias(bnext, wave);
+    } else {
+      load_bias(bnext, wave);                   // consumed after the projection
       srk_lds_barrier();                        // Ba: xn1 rows of window t are in LDS; head tiles are free
-      // ---- projection: 64 rows x 96 columns in four 16-row quarters (24 accumulator registers at a time) ----------------
+    }
+    // ---- projection: 64 rows x (16 NF) columns in four 16-row quarters ---------------------------------------------
 #pragma unroll 1
-      for (int mq = 0; mq < 4; ++mq) {
-        f32x4_t acc[6];
+    for (int mq = 0; mq < 4; ++mq) {
+      f32x4_t acc[NF];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const int row = 16 * mq + r16;
+      for (int j = 0; j < NF; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * mq + r16;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(As + row * (F_K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
+      for (int s = 0; s < 6; ++s) {
+        const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(As + row * (F_K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
 #pragma unroll
-          for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+        for (int j = 0; j < NF; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+      }
+      // fragment f: columns 16 f .. 16 f + 15 -> which = f / 12, head = (f % 12) / 2, d = 16 (f & 1) + 4 g + e
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int f = f0 + j;
+        const int which = f / 12, hh = (f - 12 * which) >> 1, d = 16 * (f & 1) + 4 * g;
+        const float sc = which == 0 ? p.scale : 1.0f;
+        const float4 bq = *reinterpret_cast<const float4*>(pbias + 16 * f + 4 * g);
+        *reinterpret_cast<uint2*>(tiles + (which * F_NH + hh) * F_TILE + row * FT + d) =
+            pack_bf4((acc[j][0] + bq.x) * sc, (acc[j][1] + bq.y) * sc, (acc[j][2] + bq.z) * sc, (acc[j][3] + bq.w) * sc);
+      }
+    }
+    srk_lds_barrier();                          // Bb: all q/k/v head tiles of the window are complete
+    // ---- attention: units u = wave, wave + 8, wave + 16 (u = 4 head + query tile) ----------------------------------
+    {
+      const int w = (int)(b_ % p.geom.nW);
+      const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
+      const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
+      unsigned char* aot = smem + (t & 1) * F_SLOT;            // the consumed xn1 slot becomes the ao tile [64][192]
+#pragma unroll 1
+      for (int k = 0; k < 3; ++k) {
+        const int u = wave + 8 * k, h = u >> 2, it = u & 3;
+        const bf16_t* Qs = tiles + (0 * F_NH + h) * F_TILE;
+        const bf16_t* Ks = tiles + (1 * F_NH + h) * F_TILE;
+        const bf16_t* Vs = tiles + (2 * F_NH + h) * F_TILE;
+        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * FT + 8 * g);
+        f32x4_t s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * FT + 8 * g), qf,
+                                                        f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) s[jt] += bnext[jt];
+        if (k < 2) load_bias(bnext, u + 8);     // next unit's bias: in flight under this unit's softmax and P.V
+        if (masked) {
+          const int labi = win_region_label(p.geom, w, 16 * it + r16);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
         }
-        // acc[j][e] = column 96 wave + 16 j + 4 g + e of row 16 mq + r16 -> head tile [token][d]
+        float mx = -3.0e38f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const int hh = hb + (j >> 1), d = 16 * (j & 1) + 4 * g;
-          bf16_t* tp = tiles + (which * F_NH + hh) * F_TILE + row * FT + d;
-          const float4 bq = *reinterpret_cast<const float4*>(bqp + 16 * j);
-          *reinterpret_cast<uint2*>(tp) = pack_bf4((acc[j][0] + bq.x) * sc, (acc[j][1] + bq.y) * sc, (acc[j][2] + bq.z) * sc,
-                                                   (acc[j][3] + bq.w) * sc);
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
+        mx = xrow_max4(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s[jt][e] = __expf(s[jt][e] - mx);
+            sum += s[jt][e];
+          }
+        const float inv = 1.0f / xrow_sum4(sum);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[jt][e] *= inv;
+        f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const uint2 lo = pack_bf4(s[2 * ss][0], s[2 * ss][1], s[2 * ss][2], s[2 * ss][3]);
+          const uint2 hi = pack_bf4(s[2 * ss + 1][0], s[2 * ss + 1][1], s[2 * ss + 1][2], s[2 * ss + 1][3]);
+          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8_t vf = f_cat4(lds_tr_read(tr_addr(Vs, FT, 32 * ss + 4 * g, 16 * dt, lane)),
+                                       lds_tr_read(tr_addr(Vs, FT, 32 * ss + 16 + 4 * g, 16 * dt, lane)));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+        // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]: 8 consecutive d per lane after the 16-lane-row swap
+        const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        *reinterpret_cast<uint4*>(aot + ((16 * it + r16) * F_CA + h * 32 + (((g & 1) << 4) | ((g >> 1) << 3))) * 2) =
+            make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+    }
+    // ---- q / k / v tiles -> global for the backward pass: tile tl = wave, wave + 7, wave + 14 (waves 0..6) ------------
+    if constexpr (!LOADER) {
+      if (p.qkv) {
+#pragma unroll 1
+        for (int tl = wave; tl < 18; tl += 7) {
+          const int which = tl / F_NH, hh = tl - which * F_NH;
+          const bf16_t* src = tiles + tl * F_TILE;
+          bf16_t* dst = p.qkv + ((which * p.B_ + b_) * F_NH + hh) * 2048;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + (lane >> 2), ch = lane & 3;
+            *reinterpret_cast<uint4*>(dst + row * 32 + ch * 8) = *reinterpret_cast<const uint4*>(src + row * FT + ch * 8);
+          }
         }
       }
-      srk_lds_barrier();                        // Bb: all q/k/v head tiles of the window are complete
-      // ---- attention of head `wave`: four 16-query tiles (attn.hip attn_fwd_kernel, one wave per tile there) ----------
-      {
-        const int w = (int)(b_ % p.geom.nW);
-        const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
-        const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
-        unsigned char* aot = smem + (t & 1) * F_SLOT;            // the consumed xn1 slot becomes the ao tile [64][192]
+    }
+    srk_lds_barrier();                          // Bc: the ao tile is complete; head tiles are no longer read
+    if constexpr (!LOADER) {                    // the window's 24 KB of ao: 24 x 1 KB over waves 0..6
+      const unsigned char* aot = smem + (t & 1) * F_SLOT;
+      bf16_t* adst = p.ao + b_ * 64 * F_CA;
 #pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-          const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * FT + 8 * g);
-          f32x4_t s[4];
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-            s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * FT + 8 * g), qf,
-                                                          f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt) s[jt] += bnext[jt];
-          if (it < 3) {                          // next tile's bias: in flight under this tile's softmax and P.V
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-              const float4 bv = *reinterpret_cast<const float4*>(bias_h + (16 * (it + 1) + r16) * 64 + 16 * jt + 4 * g);
-              bnext[jt] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
-            }
-          }
-          if (masked) {
-            const int labi = win_region_label(p.geom, w, 16 * it + r16);
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
-          }
-          float mx = -3.0e38f;
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
-          mx = f_xmax4(mx);
-          float sum = 0.f;
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              s[jt][e] = __expf(s[jt][e] - mx);
-              sum += s[jt][e];
-            }
-          const float inv = 1.0f / f_xsum4(sum);
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[jt][e] *= inv;
-          f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss) {
-            const uint2 lo = pack_bf4(s[2 * ss][0], s[2 * ss][1], s[2 * ss][2], s[2 * ss][3]);
-            const uint2 hi = pack_bf4(s[2 * ss + 1][0], s[2 * ss + 1][1], s[2 * ss + 1][2], s[2 * ss + 1][3]);
-            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-              const bf16x8_t vf = f_cat4(lds_tr_read(tr_addr(Vs, FT, 32 * ss + 4 * g, 16 * dt, lane)),
-                                         lds_tr_read(tr_addr(Vs, FT, 32 * ss + 16 + 4 * g, 16 * dt, lane)));
-              o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
-            }
-          }
-          // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]: 8 consecutive d per lane after the 16-lane-row swap
-          const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
-          const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
-          *reinterpret_cast<uint4*>(aot + ((16 * it + r16) * F_CA + h * 32 + (((g & 1) << 4) | ((g >> 1) << 3))) * 2) =
-              make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        }
-      }
-      // ---- q / k / v of this wave's head -> global, for the backward pass (1 KB contiguous per instruction).  The stores
-      // queue behind nothing this wave waits for soon: its next loads (the bias prefetch of the next window) are consumed
-      // only after that window's projection, microseconds later.
-#pragma unroll 1
-      for (int wh = 0; wh < (p.qkv ? 3 : 0); ++wh) {        // inference: q/k/v never leave the CU
-        const bf16_t* src = tiles + (wh * F_NH + h) * F_TILE;
-        bf16_t* dst = p.qkv + ((wh * p.B_ + b_) * F_NH + h) * 2048;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = i * 16 + (lane >> 2), ch = lane & 3;
-          *reinterpret_cast<uint4*>(dst + row * 32 + ch * 8) = *reinterpret_cast<const uint4*>(src + row * FT + ch * 8);
-        }
-      }
-      srk_lds_barrier();                        // Bc: the ao tile is complete; head tiles are no longer read
-      {                                         // the window's 24 KB of ao: 24 x 1 KB, four per MFMA wave
-        const unsigned char* aot = smem + (t & 1) * F_SLOT;
-        bf16_t* adst = p.ao + b_ * 64 * F_CA;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int idx = (wave * 4 + i) * 64 + lane;
-          *reinterpret_cast<uint4*>(adst + idx * 8) = *reinterpret_cast<const uint4*>(aot + idx * 16);
-        }
+      for (int i = wave; i < 24; i += 7) {
+        const int idx = i * 64 + lane;
+        *reinterpret_cast<uint4*>(adst + idx * 8) = *reinterpret_cast<const uint4*>(aot + idx * 16);
       }
     }
   }
+}
+
+__global__ __launch_bounds__(512) void qkv_attn_fwd_kernel(const FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long nwin = (p.B_ - blockIdx.x + gridDim.x - 1) / gridDim.x;     // windows of this workgroup
+  if (nwin <= 0) return;
+  // projection bias -> LDS once (no registers to spare for it; re-reading it from L2 per quarter put an exposed ~1 us
+  // round trip into every quarter); visible to everyone after the first barrier of the window loop
+  float* pbias = reinterpret_cast<float*>(smem + 2 * F_SLOT + 18 * F_TILE * 2);
+  for (int i = tid; i < 3 * F_CA; i += 512) pbias[i] = p.bias ? p.bias[i] : 0.f;
+  if (wave < 4) fused_wave<5, false>(p, smem, wave, lane, nwin);
+  else if (wave < 7) fused_wave<4, false>(p, smem, wave, lane, nwin);
+  else fused_wave<4, true>(p, smem, wave, lane, nwin);
 }
 
 int g_attn_fused = 1;
