@@ -152,7 +152,8 @@ def test_streaming_linear_wgrad_vs_torch_and_register_staged_kernel(ops, M, N, K
     assert float((out[1][0] - out[0][0]).abs().max()) < 1e-3 * max(1.0, float(ref_w.abs().max()))
 
 
-def test_fused_qkv_attention_matches_separate_kernels():
+@pytest.mark.parametrize("bs", [8, 7])       # 512 windows (two per workgroup) / 448 (uneven: one or two per workgroup)
+def test_fused_qkv_attention_matches_separate_kernels(bs):
     """csrc/attn_fused.hip (projection + attention per window, q/k/v only in LDS on the forward path) against the
     projection GEMM followed by attn_fwd_kernel: same MFMA order and rounding points -> identical outputs; the backward
     pass consumes the q/k/v that the fused kernel wrote."""
@@ -160,8 +161,8 @@ def test_fused_qkv_attention_matches_separate_kernels():
     cfg = _mid_cfg()
     sd = O.random_state_dict(cfg, seed=11, scale=1.0)
     gen = torch.Generator().manual_seed(5)
-    x = torch.rand(8, 3, 64, 64, generator=gen).cuda()           # 512 windows: shifted and unshifted blocks, masked borders
-    t = torch.rand(8, 3, 128, 128, generator=gen).cuda()
+    x = torch.rand(bs, 3, 64, 64, generator=gen).cuda()          # shifted and unshifted blocks, masked border windows
+    t = torch.rand(bs, 3, 128, 128, generator=gen).cuda()
     res = {}
     for on in (1, 0):
         check(lib().srk_set_option(b"attn_fused", on))
