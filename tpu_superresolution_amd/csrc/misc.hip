@@ -308,11 +308,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     __syncthreads();
     if (c < C) {
       const int cnt = (int)(p_end - pb < 64 ? p_end - pb : 64);
-      for (int pp = 0; pp < cnt; ++pp) {
-        const float g = gy[(pb + pp) * CP + c];
-        accb += g;
+      // eight gradient loads in flight (one dependent load per pixel made this a chain of memory round trips), patch
+      // values read as float4 broadcasts
+      for (int pp0 = 0; pp0 < cnt; pp0 += 8) {
+        float g8[8];
 #pragma unroll
-        for (int kk = 0; kk < 36; ++kk) acc[kk] += g * pl[pp * 36 + kk];
+        for (int u = 0; u < 8; ++u) g8[u] = pp0 + u < cnt ? gy[(pb + pp0 + u) * CP + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float g = g8[u];
+          accb += g;
+          const float* pr = pl + (pp0 + u) * 36;       // rows beyond cnt hold zeros (staged above)
+#pragma unroll
+          for (int t4 = 0; t4 < 9; ++t4) {
+            const float4 v = *reinterpret_cast<const float4*>(pr + 4 * t4);
+            acc[4 * t4] += g * v.x; acc[4 * t4 + 1] += g * v.y; acc[4 * t4 + 2] += g * v.z; acc[4 * t4 + 3] += g * v.w;
+          }
+        }
       }
     }
   }
@@ -668,7 +680,8 @@ int srk_launch_stem_wgrad(const float* in, const float* gy, float* dW, float* db
                           int CP, hipStream_t stream) {
   SRK_REQUIRE(C <= 256 && Cin <= 4, SRK_E_SHAPE, "stem wgrad: C=%d > 256 or Cin=%d > 4 unsupported", C, Cin);
   const long long npix = (long long)B * H * W;
-  const int ppb = 256;
+  const int ppb = 512;       // measured at cfg3: 128 -> 468 us, 256 -> 258, 512 -> 200, 1024 -> 248 (the 5040 atomics per workgroup
+                             // contend on the same 5040 addresses, so fewer, longer workgroups win until occupancy runs out)
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, stream, in, gy, dW, db, B,
                      H, W, Cin, C, CP, ppb);
   return srk_check_launch("stem_wgrad");
