@@ -111,6 +111,9 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   register-staged one (both in csrc/wgrad.hip).
  *   "conv_wgrad_taps" 2 (default) / 1 / 0: all-taps conv weight gradient with the LDS-DMA ring / register-staged
  *   (csrc/convwgrad.hip, incl. the MFMA image-head kernels), or the per-tap tiles of wgrad.hip + the VALU image head.
+ *   "wgrad_partials" 1 (default) / 0: the streaming weight-gradient kernels write their per-split partial tiles to a
+ *   scratch buffer (one per stream, allocated on first use) and a reduce kernel adds their sum to dW in a fixed
+ *   order, or every split adds into dW with fp32 atomics (order-dependent rounding, ~60 us slower per launch).
  * Unknown names return SRK_E_UNSUPPORTED. */
 int srk_set_option(const char* name, int value);
 

@@ -140,16 +140,29 @@ def test_streaming_linear_wgrad_vs_torch_and_register_staged_kernel(ops, M, N, K
     ref_w = y.float().t() @ x.float()
     ref_b = y.float().sum(0)
     out = {}
-    for on in (1, 0):
-        check(lib().srk_set_option(b"wgrad_stream", on))
-        dw, db = ops.linear_wgrad_bf16(dev(y), dev(x))
-        out[on] = (dw.cpu(), db.cpu())
-    check(lib().srk_set_option(b"wgrad_stream", 1))
-    tol = 2e-3 * max(1.0, float(ref_w.abs().max()))
-    for on in (1, 0):
-        assert float((out[on][0] - ref_w).abs().max()) < tol
-        assert float((out[on][1] - ref_b).abs().max()) < 2e-2
-    assert float((out[1][0] - out[0][0]).abs().max()) < 1e-3 * max(1.0, float(ref_w.abs().max()))
+    # (stream, rows per ring stage, nt loads, split partials via scratch + reduce kernel)
+    variants = {"ring32": (1, 32, 1, 1), "ring64": (1, 64, 0, 1), "ring32_atomics": (1, 32, 1, 0), "staged": (0, 32, 1, 1)}
+    try:
+        for name, (on, rows, nt, partials) in variants.items():
+            check(lib().srk_set_option(b"wgrad_stream", on))
+            check(lib().srk_set_option(b"wgrad_stream_rows", rows))
+            check(lib().srk_set_option(b"wgrad_stream_nt", nt))
+            check(lib().srk_set_option(b"wgrad_partials", partials))
+            dw, db = ops.linear_wgrad_bf16(dev(y), dev(x))
+            out[name] = (dw.cpu(), db.cpu())
+            if name == "ring32":          # fixed summation order: bit-identical when repeated
+                dw2, _ = ops.linear_wgrad_bf16(dev(y), dev(x))
+                assert torch.equal(dw2.cpu(), out[name][0])
+    finally:
+        check(lib().srk_set_option(b"wgrad_stream", 1))
+        check(lib().srk_set_option(b"wgrad_stream_rows", 32))
+        check(lib().srk_set_option(b"wgrad_stream_nt", 1))
+        check(lib().srk_set_option(b"wgrad_partials", 1))
+    scale = max(1.0, float(ref_w.abs().max()))
+    for name in variants:
+        assert float((out[name][0] - ref_w).abs().max()) < 2e-3 * scale, name
+        assert float((out[name][1] - ref_b).abs().max()) < 2e-2, name
+        assert float((out[name][0] - out["staged"][0]).abs().max()) < 1e-3 * scale, name
 
 
 @pytest.mark.parametrize("bs", [8, 7])       # 512 windows (two per workgroup) / 448 (uneven: one or two per workgroup)

@@ -7,7 +7,7 @@ import re
 from typing import List
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsrk.so")
+LIB_PATH = os.environ.get("SRK_LIB_PATH") or os.path.join(HERE, "libsrk.so")   # SRK_LIB_PATH: developer A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "srk.h")
 
 _lib = None

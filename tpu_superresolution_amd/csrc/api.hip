@@ -265,6 +265,19 @@ int srk_set_option(const char* name, int value) {
     srk_conv_wgrad_taps_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "wgrad_stream_rows") == 0) {
+    SRK_REQUIRE(value == 32 || value == 64, SRK_E_SHAPE, "wgrad_stream_rows: 32/64");
+    srk_wgrad_stream_tune(value, -1);
+    return SRK_OK;
+  }
+  if (strcmp(name, "wgrad_stream_nt") == 0) {
+    srk_wgrad_stream_tune(0, value != 0);
+    return SRK_OK;
+  }
+  if (strcmp(name, "wgrad_partials") == 0) {
+    srk_wgrad_partials_enable(value);
+    return SRK_OK;
+  }
   static int bm = 0, ks2 = -1, split = -1, nb = 0;
   if (strcmp(name, "gemm_stream_bm") == 0) {
     SRK_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, SRK_E_SHAPE, "gemm_stream_bm: 0/16/32/64");

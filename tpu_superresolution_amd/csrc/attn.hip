@@ -129,6 +129,20 @@ __device__ __forceinline__ void load_bias_T(f32x4_t (&bias)[4][4], const float* 
 
 // ------------------------------------------------------------------------------------------------
 // forward
+#ifndef SRK_NT_ATTN_BWD
+#define SRK_NT_ATTN_BWD 1
+#endif
+typedef unsigned srk_v4u __attribute__((ext_vector_type(4)));
+// 16 bytes that this launch reads exactly once (saved q / k / v, the incoming gradient): streaming cache policy
+__device__ __forceinline__ uint4 ld_once16(const bf16_t* p) {
+  if constexpr (SRK_NT_ATTN_BWD != 0) {
+    const srk_v4u v = __builtin_nontemporal_load(reinterpret_cast<const srk_v4u*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One 4-wave workgroup owns one (window, head) at a time; wave w handles the 16 queries of tile it = w against all
 // 64 keys (4 + 4 MFMAs).  K and V are staged once per window in LDS (V is read back transposed); the next window's
@@ -147,9 +161,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   uint4 prek = make_uint4(0, 0, 0, 0), prev = prek, preq = prek;
 #define ATTN_FWD_PREFETCH(BW)                                                                                  \
   do {                                                                                                         \
-    prek = *reinterpret_cast<const uint4*>(qkv + ((1 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);     \
-    prev = *reinterpret_cast<const uint4*>(qkv + ((2 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);     \
-    preq = *reinterpret_cast<const uint4*>(qkv + ((0 * B_ + (BW)) * nH + h) * 2048 + (16 * it + r16) * 32 + 8 * g); \
+    prek = ld_once16(qkv + ((1 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);                           \
+    prev = ld_once16(qkv + ((2 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);                           \
+    preq = ld_once16(qkv + ((0 * B_ + (BW)) * nH + h) * 2048 + (16 * it + r16) * 32 + 8 * g);                       \
   } while (0)
   if (w_begin < B_) ATTN_FWD_PREFETCH(w_begin);
 
@@ -255,10 +269,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
   uint4 preq = make_uint4(0, 0, 0, 0), prek = preq, prev = preq, preo = preq;
 #define ATTN_BWD_PREFETCH(BW)                                                                                     \
   do {                                                                                                            \
-    preq = *reinterpret_cast<const uint4*>(qkv + ((0 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);        \
-    prek = *reinterpret_cast<const uint4*>(qkv + ((1 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);        \
-    prev = *reinterpret_cast<const uint4*>(qkv + ((2 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);        \
-    preo = *reinterpret_cast<const uint4*>(dao + ((BW) * 64 + srow) * CA + h * 32 + sch * 8);                     \
+    preq = ld_once16(qkv + ((0 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);                              \
+    prek = ld_once16(qkv + ((1 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);                              \
+    prev = ld_once16(qkv + ((2 * B_ + (BW)) * nH + h) * 2048 + srow * 32 + sch * 8);                              \
+    preo = ld_once16(dao + ((BW) * 64 + srow) * CA + h * 32 + sch * 8);                                           \
   } while (0)
   if (w_begin < B_) ATTN_BWD_PREFETCH(w_begin);
 

@@ -28,6 +28,14 @@
 
 #include "kernels.h"
 
+#ifndef SRK_NT_ATTN
+#define SRK_NT_ATTN 1
+#endif
+#ifndef SRK_NT_STORE_QKV
+#define SRK_NT_STORE_QKV 1
+#endif
+typedef unsigned srk_u4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int FT = 40;                 // LDS row stride (elements) of a [64][32] bf16 head tile (as attn.hip TS)
@@ -84,7 +92,7 @@ __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* 
       const bf16_t* base = p.xn + (blockIdx.x + t * gridDim.x) * 64 * (long long)p.lda;
       const unsigned dst = smem_base + (unsigned)((t & 1) * F_SLOT);
 #pragma unroll
-      for (int i = 0; i < 24; ++i) srk_glds16(base + off[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
+      for (int i = 0; i < 24; ++i) srk_glds16<SRK_NT_ATTN != 0>(base + off[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
     }
   };
   auto load_bias = [&](f32x4_t (&b)[4], int u) {      // rel-pos bias rows of unit u = 4 h + it, this lane's 16 values
@@ -215,7 +223,11 @@ __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* 
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + (lane >> 2), ch = lane & 3;
-            *reinterpret_cast<uint4*>(dst + row * 32 + ch * 8) = *reinterpret_cast<const uint4*>(src + row * FT + ch * 8);
+            const uint4 t4 = *reinterpret_cast<const uint4*>(src + row * FT + ch * 8);
+            if constexpr (SRK_NT_STORE_QKV != 0)   // next read by the backward pass
+              __builtin_nontemporal_store(srk_u4{t4.x, t4.y, t4.z, t4.w}, reinterpret_cast<srk_u4*>(dst + row * 32 + ch * 8));
+            else
+              *reinterpret_cast<uint4*>(dst + row * 32 + ch * 8) = t4;
           }
         }
       }

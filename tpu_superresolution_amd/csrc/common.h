@@ -212,12 +212,19 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // One wave instruction writes 64 x 16 B (or 64 x 4 B) CONTIGUOUS bytes at the wave-uniform LDS byte address
 // `lds_dst` (lane l lands at lds_dst + 16 l); the SOURCE address is per lane, which is where swizzles / gathers go.
 // The instruction counts on vmcnt like any vector-memory operation and retires in issue order.
+template <bool NT = false>
 __device__ __forceinline__ void srk_glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
+  if constexpr (NT)   // streaming cache policy: for bytes this launch reads once
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
 }
 template <int N>
 __device__ __forceinline__ void srk_wait_vmcnt() {

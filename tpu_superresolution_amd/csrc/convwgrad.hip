@@ -11,6 +11,10 @@
 // fragments come from the transposing LDS read, with the same row padding as wgrad.hip.
 #include "wgrad.h"
 
+#ifndef SRK_NT_TAPS
+#define SRK_NT_TAPS 0
+#endif
+
 namespace {
 
 constexpr int CT = 64;                 // pixels per chunk: one run inside an image row (needs W % 64 == 0)
@@ -205,7 +209,8 @@ __device__ __forceinline__ const bf16_t* tr_addr_swz64(const bf16_t* tile, int r
 }
 
 template <bool SHUF>
-__global__ __launch_bounds__(256) void conv_wgrad_taps_dma_kernel(const WgradParams p, int ntiles, int chunks_per) {
+__global__ __launch_bounds__(256) void conv_wgrad_taps_dma_kernel(const WgradParams p, int ntiles, int chunks_per, float* partial,
+                                                                  int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned ring_base = (unsigned)(size_t)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_dma_kernel(const WgradPar
           const int yy = y + (lrp[i] >> 8) - 1, xx = x0 + (lrp[i] & 255) - 1;
           src = ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) ? xbase + loff[i] : zero;
         }
-        srk_glds16(src, __builtin_amdgcn_readfirstlane(dst + (wave * TD_PPW + i * 64) * 16));
+        srk_glds16<SRK_NT_TAPS != 0>(src, __builtin_amdgcn_readfirstlane(dst + (wave * TD_PPW + i * 64) * 16));
       }
     }
   };
@@ -322,21 +327,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_dma_kernel(const WgradPar
     (void)xs;
   }
 
+  if (partial != nullptr) {
+    // partial tile in accumulator order, summed over the splits by conv_wgrad_taps_reduce_kernel (see wgrad.hip)
+    f32x4_t* slab = reinterpret_cast<f32x4_t*>(partial) + ((size_t)btile * nsplit + bsplit) * WS_SLAB_VEC + (size_t)wave * 36 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) slab[(i * 9 + q) * 64] = acc[i][q];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + 16 * i + 4 * g;
+    if (partial == nullptr) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int cg = 9 * wave + q;
-      const long long col = (long long)(cg >> 2) * p.K + k0 + 16 * (cg & 3) + r16;
+      for (int q = 0; q < 9; ++q) {
+        const int cg = 9 * wave + q;
+        const long long col = (long long)(cg >> 2) * p.K + k0 + 16 * (cg & 3) + r16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, acc[i][q][e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, acc[i][q][e]);
+      }
     }
     if (do_bias && r16 == 0) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(p.db + n + e, accb[i][e]);
     }
   }
+}
+
+// sum of the nsplit partial tiles of conv_wgrad_taps_dma_kernel, added to dW (36 workgroups per 64 x 64 x 9-tap tile)
+__global__ __launch_bounds__(256) void conv_wgrad_taps_reduce_kernel(const WgradParams p, const float* __restrict__ partial, int nsplit) {
+  const int btile = blockIdx.x / 36;
+  const int v = (blockIdx.x - btile * 36) * 256 + threadIdx.x;
+  const int ntn = p.N / 64;
+  const int tn = btile % ntn, tk = btile / ntn;
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(partial) + (size_t)btile * nsplit * WS_SLAB_VEC + v;
+  f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= nsplit; s += 8) {
+    f32x4_t t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(s + u) * WS_SLAB_VEC];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += t[u];
+  }
+  for (; s < nsplit; ++s) sum += src[(size_t)s * WS_SLAB_VEC];
+  const int lane = v & 63, t = v >> 6;
+  const int q = t % 9, i = (t / 9) % 4, wave = t / 36;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int n = tn * 64 + 16 * i + 4 * g;
+  const int cg = 9 * wave + q;
+  const long long col = (long long)(cg >> 2) * p.K + tk * 64 + 16 * (cg & 3) + r16;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, sum[e]);
 }
 
 int g_taps_dma = 1;
@@ -360,8 +402,12 @@ int launch_taps_dma(const WgradParams& p, hipStream_t stream) {
   if (splits > nchunks) splits = nchunks;
   const int chunks_per = cdiv(nchunks, splits);
   splits = cdiv(nchunks, chunks_per);
+  float* partial =
+      srk_wgrad_partials_enabled() && splits > 1 ? srk_wgrad_scratch(stream, (size_t)tiles * splits * WS_SLAB_VEC * 16) : nullptr;
   srk_probe_pre(FAM_WGRAD_CONV, stream, p.flops, p.bytes);
-  hipLaunchKernelGGL((conv_wgrad_taps_dma_kernel<SHUF>), dim3(tiles * splits), dim3(256), lds, stream, p, tiles, chunks_per);
+  hipLaunchKernelGGL((conv_wgrad_taps_dma_kernel<SHUF>), dim3(tiles * splits), dim3(256), lds, stream, p, tiles, chunks_per, partial,
+                     splits);
+  if (partial) hipLaunchKernelGGL(conv_wgrad_taps_reduce_kernel, dim3(tiles * 36), dim3(256), 0, stream, p, partial, splits);
   srk_probe_post(FAM_WGRAD_CONV, stream);
   return srk_check_launch("conv wgrad (all taps, dma)");
 }

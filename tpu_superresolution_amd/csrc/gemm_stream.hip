@@ -42,7 +42,14 @@ constexpr int SBNP = SBN + 4;    // T row pitch in floats (conflict-free float4 
 constexpr int NC = SBN / 64;     // float4 per lane per row in the row-major phase
 constexpr int LDS_BUDGET = 160 * 1024;
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) { srk_glds16(gsrc, lds_dst); }
+#ifndef SRK_NT_GEMM
+#define SRK_NT_GEMM 1
+#endif
+#ifndef SRK_NT_STORE_U
+#define SRK_NT_STORE_U 1
+#endif
+typedef unsigned srk_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) { srk_glds16<SRK_NT_GEMM != 0>(gsrc, lds_dst); }
 __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -268,7 +275,11 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const long long o = (long long)m * p.ldo + n0 + 64 * c + 4 * j16;
-        *reinterpret_cast<uint2*>(p.outb + o) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+        const uint2 pu = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+        if constexpr (SRK_NT_STORE_U != 0)   // u is next read by the backward pass: keep it out of the caches
+          __builtin_nontemporal_store(srk_u2{pu.x, pu.y}, reinterpret_cast<srk_u2*>(p.outb + o));
+        else
+          *reinterpret_cast<uint2*>(p.outb + o) = pu;
         *reinterpret_cast<uint2*>(p.outb2 + o) = gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w);
       }
     } else if constexpr (EP == EP_DGELU) {

@@ -23,8 +23,16 @@ struct WgradMulti {
   int nprob;
   int m_per;            // rows per workgroup (set by the launcher)
   int tile_begin[5];    // prefix sum of tiles per problem
+  float* partial;       // streaming kernels: scratch slabs [tile][split][WS_SLAB_VEC] of 4 floats, or null (atomics)
+  int nsplit;
   WgradParams p[4];
 };
+
+constexpr int WS_SLAB_VEC = 9216;   // accumulator vectors (4 floats) of one workgroup tile: 192 x 192 or 64 x 64 x 9 taps
+float* srk_wgrad_scratch(hipStream_t stream, size_t bytes);
+void srk_wgrad_partials_enable(int on);
+void srk_wgrad_stream_tune(int rows, int nt);   // rows 32/64 (0 = keep), nt 0/1 (-1 = keep)
+int srk_wgrad_partials_enabled();
 
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);
 

@@ -12,6 +12,10 @@
 // The bias gradient comes for free from one extra MFMA column against an all-ones B fragment.
 #include "wgrad.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace {
 
 template <int TA, int TB, bool CONV>
@@ -180,15 +184,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mp) {
 }
 
 // ---- streaming variant of the 192 x 192 linear tile -------------------------------------------------------------
-// Same tile, same MFMA schedule, but the 64-row Y / X chunks arrive by LDS-DMA into a 3-deep ring (48 KB per stage):
-// two chunks (96 KB per CU) are in flight while one is consumed, instead of the single register-staged chunk of
-// wgrad_kernel, whose load latency (~2 us under load) exceeded the 0.5 us of MFMA work per chunk.  No wave stores
-// inside the loop, so every wave's vmcnt sees only its own DMAs and the counted wait is exact; one raw barrier per
-// chunk.  A DMA writes lane-linear, which rules out the padded rows: rows are 384 B and the 32-byte column pairs
-// are XOR-swizzled with (row >> 1) & 3 on the SOURCE address -- the 8 consecutive rows a half-wave transposing
-// read touches then fall in 8 different 32-byte bank windows (row stride 384 B = 1.5 x 256 B).
-constexpr int WS_STAGE_ELEMS = 2 * 64 * 192;      // Y chunk + X chunk, bf16 elements
-constexpr int WS_RING = 3;
+// Same tile, same MFMA schedule, but the Y / X chunks arrive by LDS-DMA into a ring that fills the LDS (144 KB): 6 stages
+// of 32 rows (default; up to 120 KB per CU in flight while one stage is consumed) or 3 stages of 64 rows, instead of
+// the single register-staged chunk of wgrad_kernel, whose load latency (~2 us under load) exceeded the 0.5 us of MFMA
+// work per chunk.  No wave stores inside the loop, so every wave's vmcnt sees only its own DMAs and the counted wait
+// is exact; one raw barrier per chunk.  A DMA writes lane-linear, which rules out the padded rows: rows are 384 B and
+// the 32-byte column pairs are XOR-swizzled with (row >> 1) & 3 on the SOURCE address -- the 8 consecutive rows a
+// half-wave transposing read touches then fall in 8 different 32-byte bank windows (row stride 384 B = 1.5 x 256 B).
+// The operands are read once per launch, so the DMAs carry the nt (streaming) cache policy: inside the train step
+// that is worth 35 us per launch (the reads no longer evict what the neighbouring kernels hand to each other through
+// the L2 / Infinity Cache); on its own the loader streams at 6.0 TB/s default and 6.8 TB/s nt (tools/read_bw.hip).
+// The split partials go to scratch slabs in accumulator order (1-KiB store instructions) and wgrad_reduce_kernel adds
+// their sum to dW: 9.4 M fp32 atomics per launch in 4 x 64-B segments cost ~27 us more than the slab stores, and the
+// fixed summation order makes dW reproducible run to run.
+constexpr int WS_LDS_BYTES = 147456;              // the whole ring: 3 stages of 64 rows or 6 stages of 32 rows
 
 __device__ __forceinline__ const bf16_t* tr_addr_swz(const bf16_t* tile, int rbase, int c0, int lane) {
   const int ll = lane & 15;
@@ -196,7 +205,12 @@ __device__ __forceinline__ const bf16_t* tr_addr_swz(const bf16_t* tile, int rba
   return tile + row * 192 + (((c0 >> 4) ^ ((row >> 1) & 3)) << 4) + ((ll & 3) << 2);
 }
 
+template <int ROWS, bool NT>
 __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) {
+  constexpr int STAGE_ELEMS = 2 * ROWS * 192;          // Y chunk + X chunk, bf16 elements
+  constexpr int RING = WS_LDS_BYTES / (STAGE_ELEMS * 2);
+  constexpr int NI = ROWS * 24 / 256;                  // DMA instructions per wave, chunk and operand (6 or 3)
+  constexpr int AHEAD = RING - 1;                      // chunks issued ahead of the one being consumed
   const int ntiles = mp.tile_begin[mp.nprob];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bsplit = logical / ntiles, btile = logical - bsplit * ntiles;
@@ -217,32 +231,32 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
   const int n0 = tn * 192, k0 = tk * 192;
   const int m_begin = bsplit * mp.m_per;
   const int m_end = min(p.M, m_begin + mp.m_per);
-  const int nchunk = (m_end - m_begin) / 64;
+  const int nchunk = (m_end - m_begin) / ROWS;
   if (nchunk <= 0) return;
 
-  // this wave's quarter of a stage image: 384 16-byte pieces of Y and of X (6 + 6 DMA instructions).  Which piece a
-  // lane moves in instruction i never changes: its element offset relative to the chunk's first row is computed once
-  // (with one wave per SIMD the per-chunk address arithmetic otherwise competes with the MFMAs for issue slots).
-  int yoff[6], xoff[6];
+  // this wave's quarter of a stage image: ROWS * 6 16-byte pieces of Y and of X (NI + NI DMA instructions).  Which
+  // piece a lane moves in instruction i never changes: its element offset relative to the chunk's first row is computed
+  // once (with one wave per SIMD the per-chunk address arithmetic otherwise competes with the MFMAs for issue slots).
+  int yoff[NI], xoff[NI];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int q = wave * 384 + i * 64 + lane;
+  for (int i = 0; i < NI; ++i) {
+    const int q = wave * (NI * 64) + i * 64 + lane;
     const int row = q / 24, pos = q - row * 24;
     const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
     yoff[i] = row * p.ldy + n0 + c * 8;
     xoff[i] = row * p.ldx + k0 + c * 8;
   }
   auto issue = [&](int ch) {
-    const int m0 = m_begin + ch * 64;
+    const int m0 = m_begin + ch * ROWS;
     const bf16_t* yb = p.Y + (long long)m0 * p.ldy;
     const bf16_t* xb = p.X + (long long)m0 * p.ldx;
-    const unsigned dst = ring_base + (unsigned)((ch % WS_RING) * WS_STAGE_ELEMS * 2);
+    const unsigned dst = ring_base + (unsigned)((ch % RING) * STAGE_ELEMS * 2);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      srk_glds16(yb + yoff[i], __builtin_amdgcn_readfirstlane(dst + (wave * 384 + i * 64) * 16));
+    for (int i = 0; i < NI; ++i)
+      srk_glds16<NT>(yb + yoff[i], __builtin_amdgcn_readfirstlane(dst + (wave * (NI * 64) + i * 64) * 16));
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      srk_glds16(xb + xoff[i], __builtin_amdgcn_readfirstlane(dst + 64 * 192 * 2 + (wave * 384 + i * 64) * 16));
+    for (int i = 0; i < NI; ++i)
+      srk_glds16<NT>(xb + xoff[i], __builtin_amdgcn_readfirstlane(dst + ROWS * 192 * 2 + (wave * (NI * 64) + i * 64) * 16));
   };
 
   f32x4_t acc[6][6], accb[6];
@@ -255,16 +269,20 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
   const bool do_bias = p.db != nullptr && tk == 0 && wk == 0;
   const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
-  issue(0);
-  if (nchunk > 1) issue(1);
+  for (int c = 0; c < AHEAD && c < nchunk; ++c) issue(c);
   for (int ch = 0; ch < nchunk; ++ch) {
-    if (ch + 1 < nchunk) srk_wait_vmcnt<12>(); else srk_wait_vmcnt<0>();   // chunk ch landed (ch+1 may be in flight)
+    // chunk ch has landed once at most the AHEAD - 1 chunks issued after it are outstanding
+    if (ch + AHEAD - 1 < nchunk) {
+      srk_wait_vmcnt<2 * NI * (AHEAD - 1)>();
+    } else {
+      srk_wait_vmcnt<0>();
+    }
     srk_lds_barrier();                                                       // ... for every wave; MFMA(ch-1) done everywhere
-    if (ch + 2 < nchunk) issue(ch + 2);
-    const bf16_t* ys = ring + (ch % WS_RING) * WS_STAGE_ELEMS;
-    const bf16_t* xs = ys + 64 * 192;
+    if (ch + AHEAD < nchunk) issue(ch + AHEAD);
+    const bf16_t* ys = ring + (ch % RING) * STAGE_ELEMS;
+    const bf16_t* xs = ys + ROWS * 192;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < ROWS / 32; ++ks) {
       bf16x8_t yf[6], xf[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -291,14 +309,26 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
     }
   }
 
+  if (mp.partial != nullptr) {
+    // partial tile in accumulator order ([wave][i][j][lane] x 4 floats: every store instruction writes 1 KiB
+    // contiguous); wgrad_reduce_kernel sums the splits.  Float atomics of this shape (4 x 64-B segments per
+    // instruction, 9.4 M of them per launch) cost ~60 us per launch.
+    f32x4_t* slab = reinterpret_cast<f32x4_t*>(mp.partial) + (((size_t)btile * 144 + wave * 36) * mp.nsplit + bsplit) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) slab[(size_t)(i * 6 + j) * mp.nsplit * 64] = acc[i][j];
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int n = n0 + wn * 96 + 16 * i + 4 * g;
+    if (mp.partial == nullptr) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int k = k0 + wk * 96 + 16 * j + r16;
+      for (int j = 0; j < 6; ++j) {
+        const int k = k0 + wk * 96 + 16 * j + r16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + k, acc[i][j][e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + k, acc[i][j][e]);
+      }
     }
     if (do_bias && r16 == 0) {
 #pragma unroll
@@ -307,7 +337,41 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
   }
 }
 
+// Sum of the nsplit partial tiles of wgrad_stream_kernel, added to dW.  One thread per accumulator vector
+// (9216 per tile), 36 workgroups per tile; the partials are read as 1-KiB wave rows, 8 splits in flight.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradMulti mp) {
+  const int btile = blockIdx.x / 36;
+  const int q = (blockIdx.x - btile * 36) * 256 + threadIdx.x;
+  int pi = 0;
+  while (pi + 1 < mp.nprob && btile >= mp.tile_begin[pi + 1]) ++pi;
+  const WgradParams& p = mp.p[pi];
+  const int ntn = p.N / 192;
+  const int bx = btile - mp.tile_begin[pi];
+  const int tn = bx % ntn, tk = bx / ntn;
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(mp.partial) + ((size_t)btile * 144 + (q >> 6)) * mp.nsplit * 64 + (q & 63);
+  f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= mp.nsplit; s += 8) {
+    f32x4_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(s + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; s < mp.nsplit; ++s) sum += src[s * 64];
+  const int lane = q & 63, t = q >> 6;
+  const int j = t % 6, i = (t / 6) % 6, wave = t / 36;
+  const int wn = wave >> 1, wk = wave & 1, r16 = lane & 15, g = lane >> 4;
+  const int n = tn * 192 + wn * 96 + 16 * i + 4 * g;
+  const int k = tk * 192 + wk * 96 + 16 * j + r16;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + k, sum[e]);
+}
+
 int g_wgrad_stream = 1;
+int g_wgrad_rows = 32;      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
+int g_wgrad_nt = 1;         // nt (streaming) cache policy on its operand DMAs
+int g_wgrad_partials = 1;   // split partials to scratch slabs + reduce kernel (1) or fp32 atomics straight into dW (0)
 
 template <int TA, int TB, bool CONV>
 int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
@@ -323,6 +387,8 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   }
   WgradMulti mp;
   mp.nprob = nprob;
+  mp.partial = nullptr;
+  mp.nsplit = 0;
   int tiles = 0;
   double flops = 0.0, bytes = 0.0;
   for (int i = 0; i < nprob; ++i) {
@@ -346,18 +412,25 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
     bool ok = g_wgrad_stream && M % 64 == 0;
     for (int i = 0; i < nprob; ++i) ok = ok && ps[i].ldy % 8 == 0 && ps[i].ldx % 8 == 0;
     if (ok) {
-      constexpr int slds = WS_RING * WS_STAGE_ELEMS * 2;
+      constexpr int slds = WS_LDS_BYTES;
+      using KernelFn = void (*)(const WgradMulti);
+      static const KernelFn fns[4] = {&wgrad_stream_kernel<64, false>, &wgrad_stream_kernel<64, true>, &wgrad_stream_kernel<32, false>,
+                                      &wgrad_stream_kernel<32, true>};
       static bool sconf = false;
       if (!sconf) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, slds) !=
-            hipSuccess) {
-          srk_set_error("wgrad(stream): cannot reserve %d bytes of LDS", slds);
-          return SRK_E_LAUNCH;
-        }
+        for (KernelFn f : fns)
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, slds) != hipSuccess) {
+            srk_set_error("wgrad(stream): cannot reserve %d bytes of LDS", slds);
+            return SRK_E_LAUNCH;
+          }
         sconf = true;
       }
+      const KernelFn fn = fns[(g_wgrad_rows == 32 ? 2 : 0) + (g_wgrad_nt ? 1 : 0)];
+      mp.nsplit = splits;
+      mp.partial = g_wgrad_partials && splits > 1 ? srk_wgrad_scratch(stream, (size_t)tiles * splits * WS_SLAB_VEC * 16) : nullptr;
       srk_probe_pre(fam, stream, flops, bytes);
-      hipLaunchKernelGGL(wgrad_stream_kernel, dim3(tiles * splits), dim3(256), slds, stream, mp);
+      hipLaunchKernelGGL(fn, dim3(tiles * splits), dim3(256), slds, stream, mp);
+      if (mp.partial) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tiles * 36), dim3(256), 0, stream, mp);
       srk_probe_post(fam, stream);
       return srk_check_launch("wgrad(stream)");
     }
@@ -398,6 +471,36 @@ int validate(const WgradParams& p) {
 }  // namespace
 
 void srk_wgrad_stream_enable(int on) { g_wgrad_stream = on ? 1 : 0; }
+void srk_wgrad_partials_enable(int on) { g_wgrad_partials = on ? 1 : 0; }
+void srk_wgrad_stream_tune(int rows, int nt) {
+  if (rows == 32 || rows == 64) g_wgrad_rows = rows;
+  if (nt >= 0) g_wgrad_nt = nt ? 1 : 0;
+}
+int srk_wgrad_partials_enabled() { return g_wgrad_partials; }
+
+// Scratch for the split partials of the streaming weight-gradient kernels: one buffer per stream (launches on one
+// stream are ordered, so the slabs of one launch are consumed by its reduce kernel before the next launch writes).
+float* srk_wgrad_scratch(hipStream_t stream, size_t bytes) {
+  static std::mutex mu;
+  static std::map<hipStream_t, std::pair<void*, size_t>> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& e = pool[stream];
+  if (e.second < bytes) {
+    if (e.first) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(e.first);
+    }
+    e.first = nullptr;
+    e.second = 0;
+    if (hipMalloc(&e.first, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      e.first = nullptr;
+      return nullptr;
+    }
+    e.second = bytes;
+  }
+  return static_cast<float*>(e.first);
+}
 
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
   int rc = validate(p);
