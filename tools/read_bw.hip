@@ -260,6 +260,84 @@ static void run_wgrad_mix(const void* buf, size_t bytes, int copies) {
   fflush(stdout);
 }
 
+// A streaming-GEMM-shaped pipeline without the math: 4 loader waves DMA `slot_bytes` per tile into an R-deep LDS ring
+// (R - 1 tiles in flight, one barrier per tile), 4 consumer waves store `store_bytes` per tile and, with reg_bytes > 0,
+// also load that many bytes per tile into registers one tile ahead (operands that bypass the LDS ring).
+template <bool NT>
+__global__ __launch_bounds__(512) void ring_like(const char* __restrict__ src, const char* __restrict__ src2, char* __restrict__ dst,
+                                                 int slot_bytes, int R, int store_bytes, int reg_bytes, int ntiles_total) {
+  extern __shared__ char lds[];
+  const unsigned ring_base = (unsigned)(size_t)lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = gridDim.x, gi = blockIdx.x;
+  const int nt = (ntiles_total - gi + G - 1) / G;
+  const int ni = slot_bytes / 4096;                 // DMA instructions per loader wave per tile (4 waves x 1 KiB)
+  if (wave >= 4) {
+    const int lw = wave - 4;
+    auto issue = [&](int t) {
+      const char* base = src + (size_t)(gi + (size_t)t * G) * slot_bytes;
+      const unsigned slot = ring_base + (unsigned)((t % R) * slot_bytes);
+      for (int i = 0; i < ni; ++i)
+        glds16<NT>(base + (size_t)(i * 4 + lw) * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(slot + (i * 4 + lw) * 1024));
+    };
+    for (int s = 0; s < R - 1 && s < nt; ++s) issue(s);
+    for (int t = 0; t < nt; ++t) {
+      // conservative: wait until only the tiles issued after t are outstanding (ni * (R - 2) instructions)
+      const int keep = (t + R - 2 < nt) ? ni * (R - 2) : 0;
+      if (keep >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      else if (keep >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else if (keep >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (keep >= 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+      else if (keep >= 25) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+      else if (keep >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (keep >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (keep >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (keep >= 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else if (keep >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (keep >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (t + R - 1 < nt) issue(t + R - 1);
+    }
+  } else {
+    const int nst = store_bytes / 4096, nrg = reg_bytes / 4096;   // per consumer wave: 1 KiB instructions per tile
+    f4 pre[8];
+    for (int i = 0; i < 8; ++i) pre[i] = f4{0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](int t) {
+      const f4* base = (const f4*)(src2 + (size_t)(gi + (size_t)t * G) * reg_bytes);
+      for (int i = 0; i < nrg && i < 8; ++i) pre[i] = NT ? __builtin_nontemporal_load(base + (i * 4 + wave) * 64 + lane) : base[(i * 4 + wave) * 64 + lane];
+    };
+    if (nrg) prefetch(0);
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      f4 cur[8];
+      for (int i = 0; i < 8; ++i) cur[i] = pre[i];
+      if (nrg && t + 1 < nt) prefetch(t + 1);
+      f4* out = (f4*)(dst + (size_t)(gi + (size_t)t * G) * store_bytes);
+      for (int i = 0; i < nst; ++i) out[(i * 4 + wave) * 64 + lane] = cur[i & 7];
+    }
+  }
+}
+
+template <bool NT>
+static void run_ring_like(const void* buf, size_t bytes, int slot_bytes, int R, int store_bytes, int reg_bytes) {
+  // buffer split: [DMA source | register source | store destination]
+  const size_t per_tile = (size_t)slot_bytes + reg_bytes + store_bytes;
+  int ntiles = (int)(bytes / per_tile);
+  if (ntiles > 8192 * 2) ntiles = 8192 * 2;
+  const char* src = (const char*)buf;
+  const char* src2 = src + (size_t)ntiles * slot_bytes;
+  char* dst = (char*)src2 + (size_t)ntiles * reg_bytes;
+  const size_t lds = (size_t)R * slot_bytes;
+  CK(hipFuncSetAttribute((const void*)ring_like<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  double us = time_us([&] { ring_like<NT><<<256, 512, lds>>>(src, src2, dst, slot_bytes, R, store_bytes, reg_bytes, ntiles); });
+  const double mb = (double)ntiles * per_tile * 1e-6;
+  printf("ring-like %-3s slot %5d B x R %d (%3zu KiB LDS) + regs %5d B/tile, stores %5d B/tile, %5d tiles : %8.1f us  %7.1f MB  %5.2f TB/s\n",
+         NT ? "nt" : "def", slot_bytes, R, lds / 1024, reg_bytes, store_bytes, ntiles, us, mb, mb / us);
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   size_t mb = argc > 1 ? atoi(argv[1]) : 1536;
   size_t bytes = mb << 20;
@@ -273,6 +351,25 @@ int main(int argc, char** argv) {
   int cus = prop.multiProcessorCount;
   printf("# %s, %d CUs, buffer %zu MiB\n", prop.name, cus, mb);
 
+  if (argc > 2 && argv[2][0] == 'r') {  // streaming-GEMM-shaped pipelines
+    // LNBWD K=576, 16-row tiles: A 18 KB + x 12 KB + dx_in 12 KB per tile (44 KB slots -> R 3), 12 KB stored
+    run_ring_like<true>(buf, bytes, 45056, 3, 12288, 0);
+    run_ring_like<false>(buf, bytes, 45056, 3, 12288, 0);
+    // ... with the fp32 row operands through registers: 20 KB slots -> R 7
+    run_ring_like<true>(buf, bytes, 20480, 7, 12288, 24576);
+    run_ring_like<true>(buf, bytes, 20480, 5, 12288, 24576);
+    run_ring_like<true>(buf, bytes, 20480, 3, 12288, 24576);
+    // PROJ_RES: A 6 KB + x 12 KB (20 KB slots, R 7), 12 KB stored
+    run_ring_like<true>(buf, bytes, 20480, 7, 12288, 0);
+    run_ring_like<true>(buf, bytes, 20480, 4, 12288, 0);
+    // GELU: A 6 KB (8 KB slots), 12 + 12 KB stored per 16 rows... per 32-row tile: 12 KB in, 48 KB out
+    run_ring_like<true>(buf, bytes, 12288, 8, 49152, 0);
+    // pure read / pure write shapes
+    run_ring_like<true>(buf, bytes, 45056, 3, 0, 0);
+    run_ring_like<true>(buf, bytes, 20480, 7, 0, 0);
+    run_ring_like<true>(buf, bytes, 4096, 3, 32768, 0);
+    return 0;
+  }
   if (argc > 2) {  // wgrad-like loader patterns only
     run_wgrad_mix<false>(buf, bytes, 1);
     run_wgrad_mix<true>(buf, bytes, 1);

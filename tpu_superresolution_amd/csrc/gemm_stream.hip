@@ -92,52 +92,132 @@ struct StreamCfg {
 };
 
 // ---- loader: all DMAs of one tile ------------------------------------------------------------
+// Which 16-byte piece of each operand image a lane moves in DMA instruction i never changes, so everything that depends
+// on the lane only is computed once per kernel (IssueState); what depends on the tile is uniform (a tile of BM <= 64
+// rows lies inside one window and one sample) and is computed once per tile on values the compiler keeps in SGPRs.  Per
+// DMA instruction this leaves a handful of VALU operations: timestamps showed the former per-instruction address
+// arithmetic (two integer divisions per window-ordered row) costing 1.3-1.4 us per 16-row tile of the LayerNorm-
+// backward epilogue, on the critical path of the tile loop.
 template <int EP, int KC, int BM>
-__device__ __forceinline__ void stream_issue_tile(const GemmParams& p, int m0, int n0, unsigned slot, int lw, int lane, unsigned char* smem_ptr,
-                                                  unsigned smem_base) {
+struct IssueState {
+  using C = StreamCfg<EP, KC, BM>;
+  int aoff[C::NI_A];                                   // A piece: element offset relative to row m0
+  int erow[C::NE32 > 0 ? C::NI_E32 : 1];               // fp32 row operands: tile row ...
+  int eoff[C::NE32 > 0 ? C::NI_E32 : 1];               // ... and element offset (row * ldo + column for raster rows)
+  int hoff[C::NE16 > 0 ? C::NI_E16 : 1];               // bf16 row operand: element offset relative to row m0
+  float r_nW, r_nWw, r_rps, r_ohw, r_oW;               // reciprocals of the launch-constant divisors (fdiv24)
+};
+
+// x / d for 0 <= x < 2^24, d > 0, rcp ~ 1 / d: the float quotient is off by at most one, two fix-ups make it exact
+// (~11 VALU operations instead of the ~30 of the generic 32-bit division expansion; the launcher bounds M by 2^24)
+__device__ __forceinline__ int fdiv24(int x, int d, float rcp, int& rem) {
+  int q = (int)((float)x * rcp);
+  int r = x - q * d;
+  if (r < 0) { q -= 1; r += d; }
+  if (r >= d) { q += 1; r -= d; }
+  rem = r;
+  return q;
+}
+
+template <int EP, int KC, int BM>
+__device__ __forceinline__ void issue_init(const GemmParams& p, int n0, int lw, int lane, IssueState<EP, KC, BM>& is) {
   using C = StreamCfg<EP, KC, BM>;
   constexpr int CRA = C::K / 8;
 #pragma unroll
   for (int i = 0; i < C::NI_A; ++i) {
-    const int q = i * 64 + lane;
-    if (q < C::CPW_A) {
-      const int qq = lw * C::CPW_A + q;
-      const int row = qq / CRA, pos = qq - row * CRA;
-      const int c = pos ^ (row & 7);
-      glds16(p.A + (long long)(m0 + row) * p.lda + c * 8, __builtin_amdgcn_readfirstlane(slot + (lw * C::CPW_A + i * 64) * 16));
-    }
+    const int qq = lw * C::CPW_A + i * 64 + lane;
+    const int row = qq / CRA, pos = qq - row * CRA;
+    is.aoff[i] = row * p.lda + ((pos ^ (row & 7)) << 3);
   }
-  unsigned off = slot + C::A_BYTES;
   if constexpr (C::NE32 > 0) {
 #pragma unroll
-    for (int e = 0; e < C::NE32; ++e) {
-      const float* base = (EP == EP_LNBWD) ? (e == 0 ? p.ln_x : p.outf) : p.res;
-#pragma unroll
-      for (int i = 0; i < C::NI_E32; ++i) {
-        const int q = i * 64 + lane;
-        if (q < C::CPW_E32) {
-          const int qq = lw * C::CPW_E32 + q;
-          const int row = qq / (SBN / 4), pos = qq - row * (SBN / 4);
-          const int m = m0 + row;
-          long long t = m;
-          if constexpr (EP == EP_PROJ_RES) t = win_row_to_token(p.geom, m);
-          if constexpr (EP == EP_LNBWD) t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
-          glds16(base + t * p.ldo + n0 + pos * 4, __builtin_amdgcn_readfirstlane(off + (lw * C::CPW_E32 + i * 64) * 16));
-        }
-      }
-      off += C::E32_BYTES;
+    for (int i = 0; i < C::NI_E32; ++i) {
+      const int qq = lw * C::CPW_E32 + i * 64 + lane;
+      const int row = qq / (SBN / 4), pos = qq - row * (SBN / 4);
+      is.erow[i] = row;
+      is.eoff[i] = n0 + pos * 4;
     }
   }
   if constexpr (C::NE16 > 0) {
 #pragma unroll
     for (int i = 0; i < C::NI_E16; ++i) {
-      const int q = i * 64 + lane;
-      if (q < C::CPW_E16) {
-        const int qq = lw * C::CPW_E16 + q;
-        const int row = qq / (SBN / 8), pos = qq - row * (SBN / 8);
-        glds16(p.aux + (long long)(m0 + row) * p.ldo + n0 + pos * 8, __builtin_amdgcn_readfirstlane(off + (lw * C::CPW_E16 + i * 64) * 16));
+      const int qq = lw * C::CPW_E16 + i * 64 + lane;
+      const int row = qq / (SBN / 8), pos = qq - row * (SBN / 8);
+      is.hoff[i] = row * p.ldo + n0 + pos * 8;
+    }
+  }
+  const WinGeom& og = (EP == EP_LNBWD) ? p.geom : p.xn_geom;
+  is.r_nW = 1.0f / (float)max(p.geom.nW, 1);
+  is.r_nWw = 1.0f / (float)max(p.geom.nWw, 1);
+  is.r_rps = 1.0f / (float)max(p.rows_per_sample, 1);
+  is.r_ohw = 1.0f / (float)max(og.H * og.W, 1);
+  is.r_oW = 1.0f / (float)max(og.W, 1);
+}
+
+// the window / sample a tile lies in (uniform)
+struct TileGeom {
+  int tokbase, ybase, xbase, pbase, b;   // window-ordered rows: raster token = tokbase + y * W + x
+};
+
+template <int EP, int KC, int BM>
+__device__ __forceinline__ void stream_issue_tile(const GemmParams& p, const IssueState<EP, KC, BM>& is, int m0, int n0, unsigned slot, int lw,
+                                                  int lane, unsigned char* smem_ptr, unsigned smem_base) {
+  using C = StreamCfg<EP, KC, BM>;
+  const bf16_t* abase = p.A + (long long)m0 * p.lda;
+#pragma unroll
+  for (int i = 0; i < C::NI_A; ++i)
+    if (i * 64 + lane < C::CPW_A) glds16(abase + is.aoff[i], __builtin_amdgcn_readfirstlane(slot + (lw * C::CPW_A + i * 64) * 16));
+
+  // rows in window order (proj epilogue; LayerNorm backward behind the qkv dgrad): the tile's window
+  bool win = false;
+  if constexpr (EP == EP_PROJ_RES) win = true;
+  if constexpr (EP == EP_LNBWD) win = p.ln_rows_window != 0;
+  TileGeom tg = {0, 0, 0, 0, 0};
+  if (win) {
+    const int b_ = m0 >> 6;
+    int w, wx;
+    const int b = fdiv24(b_, p.geom.nW, is.r_nW, w);
+    const int wy = fdiv24(w, p.geom.nWw, is.r_nWw, wx);
+    tg.b = b;
+    tg.tokbase = b * p.geom.H * p.geom.W;
+    tg.ybase = wy * 8 + p.geom.shift;
+    tg.xbase = wx * 8 + p.geom.shift;
+    tg.pbase = m0 & 63;
+  }
+  auto row_yx = [&](int row, int& y, int& x) {      // window-ordered tile row -> image coordinates
+    const int pp = tg.pbase + row;
+    y = tg.ybase + (pp >> 3);
+    x = tg.xbase + (pp & 7);
+    if (y >= p.geom.H) y -= p.geom.H;
+    if (x >= p.geom.W) x -= p.geom.W;
+  };
+
+  unsigned off = slot + C::A_BYTES;
+  if constexpr (C::NE32 > 0) {
+#pragma unroll
+    for (int i = 0; i < C::NI_E32; ++i) {
+      if (i * 64 + lane < C::CPW_E32) {
+        long long t = m0 + is.erow[i];
+        if (win) {
+          int y, x;
+          row_yx(is.erow[i], y, x);
+          t = tg.tokbase + y * p.geom.W + x;
+        }
+        const long long eo = t * p.ldo + is.eoff[i];
+#pragma unroll
+        for (int e = 0; e < C::NE32; ++e) {
+          const float* base = (EP == EP_LNBWD) ? (e == 0 ? p.ln_x : p.outf) : p.res;
+          glds16(base + eo, __builtin_amdgcn_readfirstlane(off + e * C::E32_BYTES + (lw * C::CPW_E32 + i * 64) * 16));
+        }
       }
     }
+    off += C::NE32 * C::E32_BYTES;
+  }
+  if constexpr (C::NE16 > 0) {
+    const bf16_t* hbase = p.aux + (long long)m0 * p.ldo;
+#pragma unroll
+    for (int i = 0; i < C::NI_E16; ++i)
+      if (i * 64 + lane < C::CPW_E16) glds16(hbase + is.hoff[i], __builtin_amdgcn_readfirstlane(off + (lw * C::CPW_E16 + i * 64) * 16));
     off += C::E16_BYTES;
   }
   if constexpr (C::AUX) {
@@ -145,30 +225,52 @@ __device__ __forceinline__ void stream_issue_tile(const GemmParams& p, int m0, i
     // rowscale) still issues one harmless load so that every loader wave retires the same number of DMAs per tile
     if (lane < BM) {
       const int m = m0 + lane;
-      long long t = m;
-      if constexpr (EP == EP_PROJ_RES) t = win_row_to_token(p.geom, m);
-      if constexpr (EP == EP_LNBWD) t = p.ln_rows_window ? win_row_to_token(p.geom, m) : m;
+      int t = m, y = 0, x = 0;
+      if (win) {
+        row_yx(lane, y, x);
+        t = tg.tokbase + y * p.geom.W + x;
+      }
+      // the tile lies inside one sample (rows_per_sample % BM == 0, checked by the launcher)
+      int srem;
+      const int samp = p.rowscale ? fdiv24(win ? tg.tokbase : m0, p.rows_per_sample, is.r_rps, srem) : 0;
       const float* src = reinterpret_cast<const float*>(p.Wt) + lane;
       if constexpr (EP == EP_LNBWD) {
-        const long long st = p.ln_stats_by_m ? m : t;
+        const int st = p.ln_stats_by_m ? m : t;
         if (lw == 0) src = p.ln_mean + st;
         if (lw == 1) src = p.ln_rstd + st;
-        if (lw == 2 && p.rowscale) src = p.rowscale + t / p.rows_per_sample;
+        if (lw == 2 && p.rowscale) src = p.rowscale + samp;
       } else {
-        if (lw == 0 && p.rowscale) src = p.rowscale + t / p.rows_per_sample;
+        if (lw == 0 && p.rowscale) src = p.rowscale + samp;
       }
       glds4(src, __builtin_amdgcn_readfirstlane(off + lw * 256));
       // row maps of the tile (consumers would otherwise redo these integer divisions per row-quad): tok = raster token of
       // tile row `lane`, ro = row of the bf16 side output (fused LayerNorm output / windowed gradient copy)
       if (lw == 3) {
-        int ro = (int)t;
-        if constexpr (EP == EP_LNBWD) {
-          if (p.ln_out_window) ro = token_to_win_row(p.geom, (int)t);
-        } else {
-          if (p.xn_out && p.xn_window) ro = token_to_win_row(p.xn_geom, (int)t);
+        int ro = t;
+        bool to_win = false;
+        if constexpr (EP == EP_LNBWD) to_win = p.ln_out_window != 0;
+        else to_win = p.xn_out != nullptr && p.xn_window != 0;
+        if (to_win) {
+          const WinGeom& og = (EP == EP_LNBWD) ? p.geom : p.xn_geom;
+          if (win) {
+            // image coordinates are already known: only the target frame's shift and window index remain
+            int yy = y - og.shift, xx = x - og.shift;
+            if (yy < 0) yy += og.H;
+            if (xx < 0) xx += og.W;
+            ro = ((tg.b * og.nW + (yy >> 3) * og.nWw + (xx >> 3)) << 6) | ((yy & 7) << 3) | (xx & 7);
+          } else {
+            // token_to_win_row(og, t) with the two divisions by launch constants done through their reciprocals
+            int rem, xx;
+            const int bb = fdiv24(t, og.H * og.W, is.r_ohw, rem);
+            int yy = fdiv24(rem, og.W, is.r_oW, xx) - og.shift;
+            xx -= og.shift;
+            if (yy < 0) yy += og.H;
+            if (xx < 0) xx += og.W;
+            ro = ((bb * og.nW + (yy >> 3) * og.nWw + (xx >> 3)) << 6) | ((yy & 7) << 3) | (xx & 7);
+          }
         }
         int* maps = reinterpret_cast<int*>(smem_ptr + (off - smem_base) + 4 * 256);
-        maps[lane] = (int)t;
+        maps[lane] = t;
         maps[64 + lane] = ro;
       }
     }
@@ -401,14 +503,20 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, in
   if (wave >= 4) {
     // =================================== loader waves =============================================
     const int lw = wave - 4;
+    IssueState<EP, KC, BM> is;
+    issue_init<EP, KC, BM>(p, n0, lw, lane, is);
     for (int s = 0; s < R - 1 && s < nt; ++s)
-      stream_issue_tile<EP, KC, BM>(p, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
+      stream_issue_tile<EP, KC, BM>(p, is, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
     for (int t = 0; t < nt; ++t) {
       // tile t has landed once at most the (R-2) tiles issued after it are outstanding
       if (t + R - 2 < nt) wait_vmcnt<C::P*(R - 2)>(); else wait_vmcnt<0>();
       lds_barrier();                                                                 // B1
-      if (t + R - 1 < nt)
-        stream_issue_tile<EP, KC, BM>(p, (gi + (t + R - 1) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((t + R - 1) % R) * C::SLOT, lw, lane, smem, smem_base);
+      // KS2: the upper-half MFMA is on the tile's critical path (the consumers wait for it at Bm), the DMA issue
+      // (~1.3 us of address arithmetic per tile) is not: it runs behind B2, beside the consumers' epilogue
+      if constexpr (!KS2) {
+        if (t + R - 1 < nt)
+          stream_issue_tile<EP, KC, BM>(p, is, (gi + (t + R - 1) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((t + R - 1) % R) * C::SLOT, lw, lane, smem, smem_base);
+      }
       if constexpr (KS2) {
         const unsigned char* As = smem + SLOTS_OFF + (t % R) * C::SLOT;
         f32x4_t acc[MF][3];
@@ -437,6 +545,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const GemmParams p, in
           }
       }
       lds_barrier();                                                                 // B2
+      if constexpr (KS2) {
+        if (t + R - 1 < nt)
+          stream_issue_tile<EP, KC, BM>(p, is, (gi + (t + R - 1) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((t + R - 1) % R) * C::SLOT, lw, lane, smem, smem_base);
+      }
     }
   } else {
     // =================================== consumer waves ===========================================
@@ -550,14 +662,16 @@ __global__ __launch_bounds__(64 * (NB + 4)) void gemm_stream_split_kernel(const 
 #pragma unroll
       for (int s = 0; s < KST; ++s) asm volatile("" ::"v"(wf[j][s]));     // retire the loads before the DMA ring starts
 
+    IssueState<EP, KC, BM> is;
+    issue_init<EP, KC, BM>(p, n0, lw, lane, is);
     for (int s = 0; s < R - 2 && s < nt; ++s)
-      stream_issue_tile<EP, KC, BM>(p, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
+      stream_issue_tile<EP, KC, BM>(p, is, (gi + s * Gm) * BM, n0, smem_base + SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
     for (int i = 0; i < nt; ++i) {
       // this wave's DMAs of tile i have landed once at most the R-3 tiles issued after it are outstanding
       if (i + R - 3 < nt) wait_vmcnt<C::P*(R - 3)>(); else wait_vmcnt<0>();
       lds_barrier();                        // barrier(i): tile i complete in LDS; epilogue(i-2) done -> its slot and T are free
       if (i + R - 2 < nt)
-        stream_issue_tile<EP, KC, BM>(p, (gi + (i + R - 2) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((i + R - 2) % R) * C::SLOT, lw, lane, smem,
+        stream_issue_tile<EP, KC, BM>(p, is, (gi + (i + R - 2) * Gm) * BM, n0, smem_base + SLOTS_OFF + ((i + R - 2) % R) * C::SLOT, lw, lane, smem,
                                       smem_base);
       const unsigned char* slot = smem + SLOTS_OFF + (i % R) * C::SLOT;
       float* T = reinterpret_cast<float*>(smem + (i & 1) * C::T_BYTES);
@@ -757,6 +871,8 @@ int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream
   if (g_num_cus < 8) return SRK_NOT_COVERED;
   if (p.N % SBN != 0 || p.M % 64 != 0 || p.lda % 8 != 0 || p.N / SBN > g_num_cus / 8) return SRK_NOT_COVERED;
   if (p.M < 64 * g_num_cus) return SRK_NOT_COVERED;            // too few tiles to fill the persistent grid
+  if (p.rowscale && (p.rows_per_sample <= 0 || p.rows_per_sample % 64 != 0)) return SRK_NOT_COVERED;   // a tile lies inside one sample
+  if (p.M >= (1 << 24)) return SRK_NOT_COVERED;                // row / token indices go through fdiv24
   switch (epilogue) {
     case EP_BF16: return dispatch_k<EP_BF16>(p, stream, {32, false, true}, {32, false, true});
     case EP_QKV: return dispatch_k<EP_QKV>(p, stream, {64, false, false}, {32, false, true});   // front-bound when split: 3 slices share A
