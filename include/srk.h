@@ -111,6 +111,8 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   register-staged one (both in csrc/wgrad.hip).
  *   "conv_wgrad_taps" 2 (default) / 1 / 0: all-taps conv weight gradient with the LDS-DMA ring / register-staged
  *   (csrc/convwgrad.hip, incl. the MFMA image-head kernels), or the per-tap tiles of wgrad.hip + the VALU image head.
+ *   "wgrad_stream_rows" 32 (default) / 64: rows per ring stage of that kernel (6 or 3 stages in the 144 KB ring);
+ *   "wgrad_stream_nt" 1 (default) / 0: streaming cache policy on its operand DMAs.
  *   "wgrad_partials" 1 (default) / 0: the streaming weight-gradient kernels write their per-split partial tiles to a
  *   scratch buffer (one per stream, allocated on first use) and a reduce kernel adds their sum to dW in a fixed
  *   order, or every split adds into dW with fp32 atomics (order-dependent rounding, ~60 us slower per launch).

@@ -49,6 +49,18 @@ constexpr int LDS_BUDGET = 160 * 1024;
 #define SRK_NT_STORE_U 1
 #endif
 typedef unsigned srk_u2 __attribute__((ext_vector_type(2)));
+typedef float srk_f4 __attribute__((ext_vector_type(4)));
+#ifndef SRK_NT_STORE_ALL
+#define SRK_NT_STORE_ALL 0
+#endif
+__device__ __forceinline__ void st_u2(bf16_t* ptr, uint2 v) {
+  if constexpr (SRK_NT_STORE_ALL != 0) __builtin_nontemporal_store(srk_u2{v.x, v.y}, reinterpret_cast<srk_u2*>(ptr));
+  else *reinterpret_cast<uint2*>(ptr) = v;
+}
+__device__ __forceinline__ void st_f4(float* ptr, float4 v) {
+  if constexpr (SRK_NT_STORE_ALL != 0) __builtin_nontemporal_store(srk_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<srk_f4*>(ptr));
+  else *reinterpret_cast<float4*>(ptr) = v;
+}
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) { srk_glds16<SRK_NT_GEMM != 0>(gsrc, lds_dst); }
 __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -360,7 +372,7 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
     if constexpr (EP == EP_BF16) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
-        *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+        st_u2(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16, pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w));
     } else if constexpr (EP == EP_QKV) {
       const long long b_ = m >> 6;
       const int tok = m & 63;
@@ -381,8 +393,8 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
         if constexpr (SRK_NT_STORE_U != 0)   // u is next read by the backward pass: keep it out of the caches
           __builtin_nontemporal_store(srk_u2{pu.x, pu.y}, reinterpret_cast<srk_u2*>(p.outb + o));
         else
-          *reinterpret_cast<uint2*>(p.outb + o) = pu;
-        *reinterpret_cast<uint2*>(p.outb2 + o) = gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w);
+          st_u2(p.outb + o, pu);
+        st_u2(p.outb2 + o, gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w));
       }
     } else if constexpr (EP == EP_DGELU) {
 #pragma unroll
@@ -391,8 +403,7 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
         float u0, u1, u2, u3;
         unpack_bf2(ua.x, u0, u1);
         unpack_bf2(ua.y, u2, u3);
-        *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16) =
-            dgelu_mul_pack4(v[c].x, v[c].y, v[c].z, v[c].w, u0, u1, u2, u3);
+        st_u2(p.outb + (long long)m * p.ldo + n0 + 64 * c + 4 * j16,  dgelu_mul_pack4(v[c].x, v[c].y, v[c].z, v[c].w, u0, u1, u2, u3));
       }
     } else if constexpr (EP == EP_PROJ_RES || EP == EP_RES) {
       const long long t_ = maps[lr];
@@ -402,9 +413,9 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
       for (int c = 0; c < NC; ++c) {
         const float4 rv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
         o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
-        *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + n0 + 64 * c + 4 * j16) = o[c];
+        st_f4(p.outf + t_ * p.ldo + n0 + 64 * c + 4 * j16, o[c]);
         if constexpr (EP == EP_RES) {
-          if (p.outb) *reinterpret_cast<uint2*>(p.outb + t_ * p.ldo + n0 + 64 * c + 4 * j16) = pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w);
+          if (p.outb) st_u2(p.outb + t_ * p.ldo + n0 + 64 * c + 4 * j16, pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w));
         }
       }
       if (p.xn_out) fused_ln_row_at<NC>(p, o, maps[64 + lr], j16, lg, lb);
@@ -443,9 +454,9 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
             cb[c][e] += dy[c][e];
           }
         }
-        *reinterpret_cast<float4*>(p.outf + t_ * p.ldo + 64 * c + 4 * j16) = make_float4(o[0], o[1], o[2], o[3]);
+        st_f4(p.outf + t_ * p.ldo + 64 * c + 4 * j16, make_float4(o[0], o[1], o[2], o[3]));
         if (p.outb)
-          *reinterpret_cast<uint2*>(p.outb + ro * p.ldo + 64 * c + 4 * j16) = pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f);
+          st_u2(p.outb + ro * p.ldo + 64 * c + 4 * j16, pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f));
       }
     }
   }
