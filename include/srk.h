@@ -125,6 +125,16 @@ int srk_set_option(const char* name, int value);
  * (zero them first); d_pred may be null; grad_scale multiplies d_pred (1.0 for a plain backward). */
 int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, float* loss, uint32_t* nonfinite,
                         int64_t n, float grad_scale, srk_stream_t stream);
+/* Validation metrics of one batch in one pass (first slice): per-image PSNR of the images clamped to [0, 1]
+ * (batch_psnr, finetune_swinir.py:69-74: 20 log10(max_val / sqrt(mse + 1e-8)), mse over the per_image = C*H*W elements of an
+ * image) and the sum of |pred - target| over the batch for the validation L1 (F.l1_loss, :66-67, used by validate :181-207).
+ * pred / target: fp32 [B][per_image].  psnr: fp32 [B] or null.  psnr_sum / abs_sum: fp32 scalars or null, ACCUMULATED (zero
+ * them before the first batch; one host read at the end of the validation loop replaces the reference's per-batch .item()).
+ * workspace: srk_batch_psnr_workspace(per_image, B) bytes of device memory owned by the caller.  Sums are formed in a fixed
+ * order (no atomics): results are reproducible.  B <= 1024. */
+int64_t srk_batch_psnr_workspace(int64_t per_image, int B);
+int srk_batch_psnr(const float* pred, const float* target, void* workspace, int B, int64_t per_image, float max_val, float* psnr,
+                   float* psnr_sum, float* abs_sum, srk_stream_t stream);
 /* sum of squares of a flat fp32 gradient, ACCUMULATED into sumsq[0] (for clip_grad_norm_ :170) */
 int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW step (:168-171, :303) on flat fp32 buffers.  The clip coefficient is

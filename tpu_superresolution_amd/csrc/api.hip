@@ -317,6 +317,20 @@ int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, f
   return srk_launch_l1_loss(pred, target, d_pred, loss, nonfinite, n, grad_scale, (hipStream_t)stream);
 }
 
+int64_t srk_batch_psnr_workspace(int64_t per_image, int B) {
+  if (per_image <= 0 || B <= 0) return 0;
+  return (int64_t)2 * sizeof(float) * B * srk_batch_psnr_chunks(per_image);
+}
+
+int srk_batch_psnr(const float* pred, const float* target, void* workspace, int B, int64_t per_image, float max_val, float* psnr,
+                   float* psnr_sum, float* abs_sum, srk_stream_t stream) {
+  REQ_PTR(pred); REQ_PTR(target); REQ_PTR(workspace);
+  SRK_REQUIRE(B > 0 && B <= 1024 && per_image > 0, SRK_E_SHAPE, "batch_psnr: B=%d (1..1024) per_image=%lld", B, (long long)per_image);
+  SRK_REQUIRE(max_val > 0.f, SRK_E_SHAPE, "batch_psnr: max_val=%g", (double)max_val);
+  return srk_launch_batch_psnr(pred, target, static_cast<float*>(workspace), B, per_image, max_val, psnr, psnr_sum, abs_sum,
+                               (hipStream_t)stream);
+}
+
 int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t stream) {
   REQ_PTR(grads); REQ_PTR(sumsq);
   return srk_launch_sumsq(grads, n, sumsq, (hipStream_t)stream);

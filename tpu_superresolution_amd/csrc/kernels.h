@@ -33,6 +33,13 @@ int srk_launch_stem_wgrad(const float* in, const float* gy, float* dW, float* db
 int srk_launch_img_grad_prep(const float* dpred, float* gy, int B, int Cimg, int Hc, int Wc, int H, int W, int r, int CoP, float inv_range, hipStream_t stream);
 int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP, int Co, int CoP, hipStream_t stream);
 int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP, int Co, int CoP, hipStream_t stream);
+// workgroups per image of the PSNR partial pass (8192 elements each, at most 64)
+inline int srk_batch_psnr_chunks(long long per_image) {
+  const long long c = (per_image + 8191) / 8192;
+  return (int)(c < 1 ? 1 : (c > 64 ? 64 : c));
+}
+int srk_launch_batch_psnr(const float* pred, const float* target, float* partial, int B, long long per_image, float max_val,
+                          float* psnr, float* psnr_sum, float* abs_sum, hipStream_t stream);
 int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream);
 int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStream_t stream);
 int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream);

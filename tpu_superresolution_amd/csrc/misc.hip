@@ -2,6 +2,7 @@
 // shuffle / mask / relative-position index), weight pack / gradient unpack, image pre/post
 // processing, the 3-channel stem conv, small-Cout conv gradients, L1 loss, fused AdamW + global-norm
 // clip, and the on-device probe of the transposing LDS read.
+#include "kernels.h"
 #include "pack.h"
 #include "wgrad.h"
 
@@ -539,6 +540,65 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Validation metrics in one pass over (pred, target): per-image PSNR of the clamped images (batch_psnr,
+// finetune_swinir.py:69-74: 20 log10(max / sqrt(mse + 1e-8)), mse over C*H*W of one image) and the sum of |pred - target|
+// of the UNclamped values for the L1 loss (F.l1_loss, :66-67, :196-197).  Stage 1: workgroup (chunk, image) writes its
+// partial sums; stage 2: one thread per image adds the partials in a fixed order (reproducible, no atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void psnr_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           float* __restrict__ partial, long long per_image) {
+  __shared__ float red[2][4];
+  const long long base = (long long)blockIdx.y * per_image;
+  float sq = 0.f, ab = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_image; i += (long long)gridDim.x * blockDim.x) {
+    const float p = pred[base + i], t = target[base + i];
+    const float d = fminf(fmaxf(p, 0.f), 1.f) - fminf(fmaxf(t, 0.f), 1.f);
+    sq = fmaf(d, d, sq);
+    ab += fabsf(p - t);
+  }
+  sq = wave_sum64(sq);
+  ab = wave_sum64(ab);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sq;
+    red[1][threadIdx.x >> 6] = ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = partial + 2 * ((long long)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ void psnr_finish_kernel(const float* __restrict__ partial, int chunks, int B, long long per_image, float max_val,
+                                   float* __restrict__ psnr, float* __restrict__ psnr_sum, float* __restrict__ abs_sum) {
+  // one workgroup, thread b = image b; the batch totals are added by thread 0 in image order
+  __shared__ float sh_psnr[1024], sh_abs[1024];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float sq = 0.f, ab = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+      sq += partial[2 * ((long long)b * chunks + c)];
+      ab += partial[2 * ((long long)b * chunks + c) + 1];
+    }
+    const float mse = sq / (float)per_image;
+    const float v = 20.0f * log10f(max_val / sqrtf(mse + 1e-8f));
+    if (psnr) psnr[b] = v;
+    sh_psnr[b] = v;
+    sh_abs[b] = ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ps = 0.f, as = 0.f;
+    for (int b = 0; b < B; ++b) {
+      ps += sh_psnr[b];
+      as += sh_abs[b];
+    }
+    if (psnr_sum) *psnr_sum += ps;
+    if (abs_sum) *abs_sum += as;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // global-norm clip + AdamW (torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW semantics,
 // finetune_swinir.py:168-171, :303)
 // ------------------------------------------------------------------------------------------------
@@ -770,6 +830,14 @@ int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, flo
   hipLaunchKernelGGL(l1_loss_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, stream, pred, target, dpred, loss_sum,
                      nonfinite, n, 1.0f / (float)n, grad_scale);
   return srk_check_launch("l1_loss");
+}
+
+int srk_launch_batch_psnr(const float* pred, const float* target, float* partial, int B, long long per_image, float max_val,
+                          float* psnr, float* psnr_sum, float* abs_sum, hipStream_t stream) {
+  const int chunks = srk_batch_psnr_chunks(per_image);
+  hipLaunchKernelGGL(psnr_partial_kernel, dim3(chunks, B), dim3(256), 0, stream, pred, target, partial, per_image);
+  hipLaunchKernelGGL(psnr_finish_kernel, dim3(1), dim3(256), 0, stream, partial, chunks, B, per_image, max_val, psnr, psnr_sum, abs_sum);
+  return srk_check_launch("batch_psnr");
 }
 
 int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream) {

@@ -73,13 +73,27 @@ def train_one_epoch(model, loader, optimizer, device, sync=None, check_finite=Tr
 def validate(model, loader, device):
     model.eval()
     total, n, sum_psnr, n_imgs, t0 = 0.0, 0, 0.0, 0, time.time()
+    on_gpu = torch.device(device).type == "cuda"
+    if on_gpu:
+        # fused L1 + per-image PSNR pass (csrc/misc.hip psnr_*_kernel); the sums stay on the device until the loop ends
+        # (the reference reads two scalars back per batch, finetune_swinir.py:196-201)
+        from . import ops
+        psnr_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        l1_acc = torch.zeros(1, dtype=torch.float32, device=device)
     for lr, hr in loader:
         lr, hr = lr.to(device, non_blocking=True), hr.to(device, non_blocking=True)
         out = model(lr)
-        total += float(l1_loss(out, hr))
+        if on_gpu:
+            batch_abs = torch.zeros(1, dtype=torch.float32, device=device)
+            ops.batch_psnr(out.float(), hr.float(), 1.0, psnr_sum=psnr_acc, abs_sum=batch_abs)
+            l1_acc += batch_abs / out.numel()          # mean over the batch, like F.l1_loss; batches may differ in size
+        else:
+            total += float(l1_loss(out, hr))
+            sum_psnr += float(batch_psnr(out, hr).sum())
         n += 1
-        sum_psnr += float(batch_psnr(out, hr).sum())
         n_imgs += lr.size(0)
+    if on_gpu:
+        total, sum_psnr = float(l1_acc), float(psnr_acc)
     return total / max(1, n), sum_psnr / max(1, n_imgs), time.time() - t0
 
 

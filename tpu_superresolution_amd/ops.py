@@ -173,6 +173,20 @@ def probe_trread(tile: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def batch_psnr(pred: torch.Tensor, target: torch.Tensor, max_val: float = 1.0, psnr_sum: Optional[torch.Tensor] = None,
+               abs_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-image PSNR [B] of fp32 [B, ...] images (finetune_swinir.py:69-74) in one fused pass; optionally ACCUMULATES the
+    batch's PSNR sum and sum |pred - target| into the given fp32 scalars (validation loop without per-batch host syncs)."""
+    assert pred.shape == target.shape and pred.dtype == torch.float32 and target.dtype == torch.float32
+    pred, target = pred.contiguous(), target.contiguous()
+    B = pred.shape[0]
+    per_image = pred.numel() // B
+    ws = torch.empty(int(lib().srk_batch_psnr_workspace(per_image, B)), dtype=torch.uint8, device=pred.device)
+    out = torch.empty(B, dtype=torch.float32, device=pred.device)
+    check(lib().srk_batch_psnr(_p(pred), _p(target), _p(ws), B, per_image, float(max_val), _p(out), _p(psnr_sum), _p(abs_sum), _stream()))
+    return out
+
+
 def l1_loss_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
     """-> (loss fp32 [1], d_pred | None, nonfinite int32 [1])   (finetune_swinir.py:66-67, :133-143)."""
     loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
