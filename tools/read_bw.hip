@@ -173,6 +173,14 @@ __global__ __launch_bounds__(256) void read_wgrad_mix(const MixParams mp) {
   }
 }
 
+__global__ void fill_random(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + 12345u;
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    p[i] = (x & 0x7fff7fffu) | 0x30003000u;      // two finite bf16 values of mixed magnitude
+  }
+}
+
 template <typename F>
 static double time_us(F launch, int reps = 10) {
   hipEvent_t e0, e1;
@@ -346,10 +354,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&buf, bytes));
   CK(hipMalloc(&sink, 4));
   CK(hipMemset(buf, 0, bytes));
+  const bool randfill = argc > 3;
+  if (randfill) {
+    fill_random<<<4096, 256>>>((unsigned*)buf, bytes / 4);
+    CK(hipDeviceSynchronize());
+  }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   int cus = prop.multiProcessorCount;
-  printf("# %s, %d CUs, buffer %zu MiB\n", prop.name, cus, mb);
+  printf("# %s, %d CUs, buffer %zu MiB, %s data\n", prop.name, cus, mb, randfill ? "pseudo-random" : "all-zero");
 
   if (argc > 2 && argv[2][0] == 'r') {  // streaming-GEMM-shaped pipelines
     // LNBWD K=576, 16-row tiles: A 18 KB + x 12 KB + dx_in 12 KB per tile (44 KB slots -> R 3), 12 KB stored
