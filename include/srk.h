@@ -125,6 +125,15 @@ int srk_set_option(const char* name, int value);
  * (zero them first); d_pred may be null; grad_scale multiplies d_pred (1.0 for a plain backward). */
 int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, float* loss, uint32_t* nonfinite,
                         int64_t n, float grad_scale, srk_stream_t stream);
+/* Data path on the device (first slice): the paired transform of the training set -- ToImage +
+ * ToDtype(scale=True), _ensure_3ch and paired_random_crop (finetune_swinir.py:80-110) -- from a pool of pre-decoded 8-bit
+ * images in device memory.  pool: the images back to back, each [H][W][C] uint8 with C = 1 or 3.  lr_desc / hr_desc: B
+ * descriptors of six int64 {byte offset in pool, H, W, C, top, left} in DEVICE memory; the caller draws (top, left) for the LR
+ * side (the reference's random.randint pair, :101-102), the HR descriptor carries (top * scale, left * scale) and must lie
+ * inside its image (the caller checks; the kernel does not).  lr_out: fp32 [B][3][P][P], hr_out: fp32 [B][3][P*scale][P*scale];
+ * value = u8 / 255 in IEEE fp32, a gray image is repeated into three channels: bit-identical to the host transform. */
+int srk_paired_crop_u8(const uint8_t* pool, const int64_t* lr_desc, const int64_t* hr_desc, float* lr_out, float* hr_out, int B,
+                       int lr_patch, int scale, srk_stream_t stream);
 /* Validation metrics of one batch in one pass (first slice): per-image PSNR of the images clamped to [0, 1]
  * (batch_psnr, finetune_swinir.py:69-74: 20 log10(max_val / sqrt(mse + 1e-8)), mse over the per_image = C*H*W elements of an
  * image) and the sum of |pred - target| over the batch for the validation L1 (F.l1_loss, :66-67, used by validate :181-207).

@@ -63,3 +63,43 @@ def test_finetune_script_one_epoch(tmp_path, capsys, monkeypatch):
     F.main(["--data_root", str(tmp_path), "--scale", "X4", "--epochs", "1", "--batch_size", "2", "--workers", "0",
             "--weights", str(tmp_path / "w.pth"), "--freeze_regex", "conv_first|layers\\.0"])
     assert "[weights] missing=0, unexpected=0" in capsys.readouterr().out
+
+
+def test_device_pool_loader_epochs_and_rank_shards():
+    """DevicePoolLoader: shuffle + drop_last per epoch, disjoint strided rank shards of one permutation (host logic only)."""
+    from tpu_superresolution_amd.finetune_swinir import DevicePoolLoader
+
+    class FakePool:
+        def __len__(self):
+            return 23
+
+        def sample(self, idx):
+            return list(idx)
+
+    seen = []
+    for r in range(2):
+        ld = DevicePoolLoader(FakePool(), 4, r, 2, seed=7)
+        ld.set_epoch(3)
+        batches = list(ld)
+        assert len(batches) == len(ld) == 2 and all(len(b) == 4 for b in batches)
+        seen += sum(batches, [])
+    assert len(seen) == len(set(seen)) == 16
+    one = DevicePoolLoader(FakePool(), 5)
+    e0 = sum(list(one), [])
+    one.set_epoch(1)
+    e1 = sum(list(one), [])
+    assert len(e0) == len(e1) == 20 and e0 != e1 and e0 == sum(list(DevicePoolLoader(FakePool(), 5)), [])
+
+
+@pytest.mark.gpu
+def test_finetune_script_with_the_training_set_on_the_device(tmp_path, capsys, monkeypatch):
+    """--gpu_data: pre-decoded pool + device crop instead of the DataLoader; same prints and checkpoint layout."""
+    from tpu_superresolution_amd import finetune_swinir as F
+    make_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    F.main(["--data_root", str(tmp_path), "--scale", "X4", "--epochs", "2", "--batch_size", "2", "--workers", "0", "--lr", "1e-4",
+            "--gpu_data"])
+    out = capsys.readouterr().out
+    assert "[gpu_data] 6 pairs" in out and "[X4] epoch 002/2" in out and "[done] best_val_loss=" in out
+    ck = torch.load(tmp_path / "bestpsnr_swinir_finetune_X4.pt", map_location="cpu", weights_only=False)
+    assert set(ck) >= {"model", "epoch", "best_val_psnr", "val_loss", "args"} and ck["args"]["gpu_data"] is True

@@ -317,6 +317,16 @@ int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, f
   return srk_launch_l1_loss(pred, target, d_pred, loss, nonfinite, n, grad_scale, (hipStream_t)stream);
 }
 
+int srk_paired_crop_u8(const uint8_t* pool, const int64_t* lr_desc, const int64_t* hr_desc, float* lr_out, float* hr_out, int B,
+                       int lr_patch, int scale, srk_stream_t stream) {
+  REQ_PTR(pool); REQ_PTR(lr_desc); REQ_PTR(hr_desc); REQ_PTR(lr_out); REQ_PTR(hr_out);
+  SRK_REQUIRE(B > 0 && B <= 65535 && lr_patch > 0 && scale > 0 && (long long)lr_patch * scale <= 8192, SRK_E_SHAPE,
+              "paired_crop: B=%d patch=%d scale=%d", B, lr_patch, scale);
+  int rc = srk_launch_crop_u8(pool, reinterpret_cast<const long long*>(lr_desc), lr_out, B, lr_patch, (hipStream_t)stream);
+  if (rc) return rc;
+  return srk_launch_crop_u8(pool, reinterpret_cast<const long long*>(hr_desc), hr_out, B, lr_patch * scale, (hipStream_t)stream);
+}
+
 int64_t srk_batch_psnr_workspace(int64_t per_image, int B) {
   if (per_image <= 0 || B <= 0) return 0;
   return (int64_t)2 * sizeof(float) * B * srk_batch_psnr_chunks(per_image);

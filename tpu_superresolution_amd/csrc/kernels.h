@@ -38,6 +38,7 @@ inline int srk_batch_psnr_chunks(long long per_image) {
   const long long c = (per_image + 8191) / 8192;
   return (int)(c < 1 ? 1 : (c > 64 ? 64 : c));
 }
+int srk_launch_crop_u8(const unsigned char* pool, const long long* desc, float* out, int B, int patch, hipStream_t stream);
 int srk_launch_batch_psnr(const float* pred, const float* target, float* partial, int B, long long per_image, float max_val,
                           float* psnr, float* psnr_sum, float* abs_sum, hipStream_t stream);
 int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream);

@@ -599,6 +599,30 @@ __global__ void psnr_finish_kernel(const float* __restrict__ partial, int chunks
 }
 
 // ------------------------------------------------------------------------------------------------
+// Data path (first slice): paired crop + uint8 -> [0, 1] float + gray -> 3 channels on the device, from a
+// pool of pre-decoded 8-bit images.  Restates pil_to_tensor01 / ensure_3ch / paired_random_crop
+// (finetune_swinir.py:80-110): value = (float)u8 / 255 (IEEE division, bit-exact with the host form), C = 1 repeated
+// three times, LR window (top, left) of size P, HR window (top * s, left * s) of size P * s.  One descriptor per sample
+// and side: {byte offset of the image in the pool, H, W, C, top, left}.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_u8_kernel(const unsigned char* __restrict__ pool, const long long* __restrict__ desc,
+                                                      float* __restrict__ out, int patch) {
+  const long long* d = desc + 6 * (long long)blockIdx.y;
+  const unsigned char* img = pool + d[0];
+  const int W = (int)d[2], C = (int)d[3], top = (int)d[4], left = (int)d[5];
+  float* o = out + (long long)blockIdx.y * 3 * patch * patch;
+  const int n = patch * patch;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int y = i / patch, x = i - y * patch;
+    const unsigned char* px = img + ((long long)(top + y) * W + (left + x)) * C;
+    const float c0 = (float)px[0] / 255.0f;
+    o[i] = c0;
+    o[n + i] = C == 1 ? c0 : (float)px[1] / 255.0f;
+    o[2 * n + i] = C == 1 ? c0 : (float)px[2] / 255.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // global-norm clip + AdamW (torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW semantics,
 // finetune_swinir.py:168-171, :303)
 // ------------------------------------------------------------------------------------------------
@@ -830,6 +854,12 @@ int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, flo
   hipLaunchKernelGGL(l1_loss_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, stream, pred, target, dpred, loss_sum,
                      nonfinite, n, 1.0f / (float)n, grad_scale);
   return srk_check_launch("l1_loss");
+}
+
+int srk_launch_crop_u8(const unsigned char* pool, const long long* desc, float* out, int B, int patch, hipStream_t stream) {
+  const int chunks = (patch * patch + 2047) / 2048;
+  hipLaunchKernelGGL(crop_u8_kernel, dim3(chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks), B), dim3(256), 0, stream, pool, desc, out, patch);
+  return srk_check_launch("crop_u8");
 }
 
 int srk_launch_batch_psnr(const float* pred, const float* target, float* partial, int B, long long per_image, float max_val,

@@ -56,6 +56,29 @@ def make_loader(ds, batch_size, workers, pin=True, shuffle=False, drop_last=Fals
     return DataLoader(**kw)
 
 
+class DevicePoolLoader:
+    """Drop-in for the training DataLoader when the training set is held pre-decoded in GPU memory (`--gpu_data`,
+    sr_datasets.DevicePairPool): same epoch semantics as DataLoader(shuffle=True, drop_last=True) with an optional
+    DistributedSampler-style rank shard (per-epoch permutation from torch.Generator(seed + epoch), ranks take strided
+    slices of it); the crop corners come from the process-global `random`, as in the host transform."""
+
+    def __init__(self, pool, batch_size: int, rank: int = 0, world: int = 1, seed: int = 0):
+        self.pool, self.batch_size, self.rank, self.world, self.seed, self.epoch = pool, batch_size, rank, world, seed, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self):
+        return (len(self.pool) // self.world) // self.batch_size
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        perm = torch.randperm(len(self.pool), generator=g).tolist()
+        mine = perm[self.rank:len(perm) - len(perm) % self.world:self.world] if self.world > 1 else perm
+        for b in range(len(self)):
+            yield self.pool.sample(mine[b * self.batch_size:(b + 1) * self.batch_size])
+
+
 def train_one_epoch(model, loader, optimizer, device, sync=None, check_finite=True):
     model.train()
     total, n, t0 = 0.0, 0, time.time()
@@ -123,6 +146,8 @@ def main(argv=None):
     ap.add_argument("--min_lr", type=float, default=2e-6)
     ap.add_argument("--grad_clip", type=float, default=1.0)
     ap.add_argument("--drop_path_rate", type=float, default=0.1)      # additive
+    ap.add_argument("--gpu_data", action="store_true",
+                    help="additive: decode the 8-bit training set once into GPU memory and crop/convert on the device")
     args = ap.parse_args(argv)
 
     rank, world, local = init_from_env()
@@ -143,6 +168,13 @@ def main(argv=None):
     sampler = DistributedSampler(train_ds, num_replicas=world, rank=rank, shuffle=True, seed=args.seed) if world > 1 else None
     train_loader = make_loader(train_ds, args.batch_size, args.workers, pin=not args.no_pin, shuffle=True, drop_last=True,
                                persistent=not args.no_persistent, sampler=sampler)
+    if args.gpu_data:
+        from .sr_datasets import DevicePairPool
+        raw = Shuffled2DPaired(args.data_root, split="train", scale=args.scale, transform_pair=None)
+        pool = DevicePairPool((raw[i] for i in range(len(raw))), args.lr_patch, scale_int, device=device)
+        train_loader = sampler = DevicePoolLoader(pool, args.batch_size, rank, world, args.seed)
+        if rank == 0:
+            print(f"[gpu_data] {len(pool)} pairs, {pool.pool.numel() / 2**20:.1f} MiB of uint8 on the device")
     valid_loader = make_loader(valid_ds, max(1, args.batch_size // 2), args.workers, pin=not args.no_pin, shuffle=False,
                                drop_last=False, persistent=not args.no_persistent)
 

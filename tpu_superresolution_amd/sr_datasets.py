@@ -113,3 +113,60 @@ class PairTransformValid:
 
     def __call__(self, lr_pil, hr_pil):
         return ensure_3ch(pil_to_tensor01(lr_pil)), ensure_3ch(pil_to_tensor01(hr_pil))
+
+
+# ---- device-resident training set (first slice) ---------------------------------------------------------
+class DevicePairPool:
+    """Pre-decoded 8-bit LR/HR pairs in GPU memory + the paired train transform as one kernel pair per batch
+    (`srk_paired_crop_u8`).  `sample(indices)` draws the crop corners with the same two `random.randint` calls per sample, in
+    the same order, as `paired_random_crop` (finetune_swinir.py:96-110), so a host pipeline and this pool produce identical
+    batches from the same `random` state.  16-bit images are not supported here (use the host transform)."""
+
+    def __init__(self, pairs, lr_patch: int, scale: int, device="cuda"):
+        """pairs: iterable of (lr, hr) PIL images or uint8 arrays [H,W] / [H,W,1|3]."""
+        self.lr_patch, self.scale, self.device = int(lr_patch), int(scale), torch.device(device)
+        chunks, self.meta, off = [], [], 0
+        for lr, hr in pairs:
+            entry = []
+            for img in (lr, hr):
+                a = np.ascontiguousarray(np.asarray(img))
+                if a.dtype != np.uint8:
+                    raise ValueError(f"DevicePairPool holds 8-bit images only, got {a.dtype}")
+                if a.ndim == 2:
+                    a = a[:, :, None]
+                if a.ndim != 3 or a.shape[2] not in (1, 3):
+                    raise ValueError(f"Expected C=1 or C=3, got shape {a.shape}")
+                entry.append((off, a.shape[0], a.shape[1], a.shape[2]))
+                chunks.append(a.reshape(-1))
+                off += a.size
+            (_, lh, lw, _), (_, hh, hw, _) = entry
+            if lh < self.lr_patch or lw < self.lr_patch:
+                raise ValueError(f"LR image too small for patch {self.lr_patch}: lr_size=({lh},{lw})")
+            if hh < lh * self.scale or hw < lw * self.scale:
+                raise ValueError(f"HR image ({hh},{hw}) smaller than scale x LR ({lh},{lw})")
+            self.meta.append(tuple(entry))
+        if not self.meta:
+            raise ValueError("DevicePairPool: no images")
+        self.pool = torch.from_numpy(np.concatenate(chunks)).to(self.device)
+
+    def __len__(self):
+        return len(self.meta)
+
+    def sample(self, indices):
+        """-> (lr [B,3,P,P], hr [B,3,P*s,P*s]) fp32 on the device; advances the global `random` state like the host transform."""
+        from ._lib import check, lib
+        P, s = self.lr_patch, self.scale
+        ld, hd = [], []
+        for i in indices:
+            (lo, lh, lw, lc), (ho, hh, hw, hc) = self.meta[int(i)]
+            top, left = random.randint(0, lh - P), random.randint(0, lw - P)
+            ld.append((lo, lh, lw, lc, top, left))
+            hd.append((ho, hh, hw, hc, top * s, left * s))
+        B = len(ld)
+        desc = torch.tensor(ld + hd, dtype=torch.int64).to(self.device)
+        lr = torch.empty(B, 3, P, P, dtype=torch.float32, device=self.device)
+        hr = torch.empty(B, 3, P * s, P * s, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib().srk_paired_crop_u8(self.pool.data_ptr(), desc[:B].data_ptr(), desc[B:].data_ptr(), lr.data_ptr(), hr.data_ptr(),
+                                       B, P, s, st))
+        return lr, hr
