@@ -113,9 +113,10 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   (csrc/convwgrad.hip, incl. the MFMA image-head kernels), or the per-tap tiles of wgrad.hip + the VALU image head.
  *   "wgrad_stream_rows" 32 (default) / 64: rows per ring stage of that kernel (6 or 3 stages in the 144 KB ring);
  *   "wgrad_stream_nt" 1 (default) / 0: streaming cache policy on its operand DMAs.
- *   "wgrad_partials" 1 (default) / 0: the streaming weight-gradient kernels write their per-split partial tiles to a
- *   scratch buffer (one per stream, allocated on first use) and a reduce kernel adds their sum to dW in a fixed
- *   order, or every split adds into dW with fp32 atomics (order-dependent rounding, ~60 us slower per launch).
+ *   "wgrad_partials" 1 (default) / 0: the streaming weight-gradient kernels write their per-split partial tiles to the
+ *   caller's workspace (srk_set_wgrad_workspace; the model executor uses a region of its own workspace) and a reduce
+ *   kernel adds their sum to dW in a fixed order, or every split adds into dW with fp32 atomics (order-dependent
+ *   rounding, ~20 us slower per launch; also what happens when no workspace is registered).
  * Unknown names return SRK_E_UNSUPPORTED. */
 int srk_set_option(const char* name, int value);
 
@@ -125,6 +126,14 @@ int srk_set_option(const char* name, int value);
  * (zero them first); d_pred may be null; grad_scale multiplies d_pred (1.0 for a plain backward). */
 int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, float* loss, uint32_t* nonfinite,
                         int64_t n, float grad_scale, srk_stream_t stream);
+/* Optional workspace of the stand-alone weight-gradient entry points (srk_linear_wgrad_bf16, srk_conv3x3_wgrad_bf16):
+ * srk_wgrad_workspace_bytes() bytes of device memory owned by the caller, registered for the CALLING THREAD until replaced
+ * (null / 0 unregisters).  With it the row-splits of a weight-gradient tile are summed in a fixed order (reproducible dW);
+ * without it they are added with fp32 atomics.  The library never allocates device memory itself.  srk_swinir_backward
+ * does not need this: it carves the region out of its own workspace. */
+int64_t srk_wgrad_workspace_bytes(void);
+int srk_set_wgrad_workspace(void* workspace, int64_t bytes);
+
 /* Data path on the device (first slice): the paired transform of the training set -- ToImage +
  * ToDtype(scale=True), _ensure_3ch and paired_random_crop (finetune_swinir.py:80-110) -- from a pool of pre-decoded 8-bit
  * images in device memory.  pool: the images back to back, each [H][W][C] uint8 with C = 1 or 3.  lr_desc / hr_desc: B

@@ -190,3 +190,35 @@ def test_fused_qkv_attention_matches_separate_kernels(bs):
     for n in res[0][1]:
         rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
         assert rel <= 1e-4, f"{n}: {rel:.3e}"            # fp32 atomics in the weight gradients are order-dependent
+
+
+def test_wgrad_workspace_is_the_callers_and_optional(ops):
+    """The library never allocates: with a registered workspace the row-splits are reduced in a fixed order (bit-identical
+    when repeated), without one (null registration) the same entry point falls back to fp32 atomics -- both correct."""
+    from tpu_superresolution_amd._lib import check, lib
+    torch.manual_seed(5)
+    M, N, K = 16384, 192, 192
+    y, x = dev(bf(torch.randn(M, N) * 0.1)), dev(bf(torch.randn(M, K)))
+    ref = y.float().t() @ x.float()
+    st = torch.cuda.current_stream().cuda_stream
+    assert int(lib().srk_wgrad_workspace_bytes()) == 256 * 9216 * 16
+    assert lib().srk_set_wgrad_workspace(None, 64) < 0                      # null pointer with a size
+
+    def run_raw():
+        dw = torch.zeros(N, K, device="cuda")
+        check(lib().srk_linear_wgrad_bf16(y.data_ptr(), x.data_ptr(), dw.data_ptr(), None, M, N, K, st))
+        return dw
+
+    check(lib().srk_set_wgrad_workspace(None, 0))
+    a1 = run_raw()                                                          # atomics
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    check(lib().srk_set_wgrad_workspace(small.data_ptr(), small.numel()))   # too small: atomics again
+    a2 = run_raw()
+    ws = torch.empty(int(lib().srk_wgrad_workspace_bytes()), dtype=torch.uint8, device="cuda")
+    check(lib().srk_set_wgrad_workspace(ws.data_ptr(), ws.numel()))
+    b1, b2 = run_raw(), run_raw()
+    check(lib().srk_set_wgrad_workspace(None, 0))
+    tol = 2e-3 * float(ref.abs().max())
+    for got in (a1, a2, b1):
+        assert float((got - ref).abs().max()) < tol
+    assert torch.equal(b1, b2)

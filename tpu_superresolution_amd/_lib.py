@@ -65,6 +65,8 @@ _SIGNATURES = {
     "srk_probe_begin": (_i, [_i, _i]),
     "srk_probe_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "srk_l1_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
+    "srk_wgrad_workspace_bytes": (_i64, []),
+    "srk_set_wgrad_workspace": (_i, [_vp, _i64]),
     "srk_paired_crop_u8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srk_batch_psnr_workspace": (_i64, [_i64, _i]),
     "srk_batch_psnr": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "kernels.h"
+#include "wgrad.h"
 
 static thread_local char g_err[512] = "";
 
@@ -315,6 +316,15 @@ int srk_l1_loss_fwd_bwd(const float* pred, const float* target, float* d_pred, f
   REQ_PTR(pred); REQ_PTR(target); REQ_PTR(loss); REQ_PTR(nonfinite);
   SRK_REQUIRE(n > 0, SRK_E_SHAPE, "l1_loss: n=%lld", (long long)n);
   return srk_launch_l1_loss(pred, target, d_pred, loss, nonfinite, n, grad_scale, (hipStream_t)stream);
+}
+
+int64_t srk_wgrad_workspace_bytes(void) { return (int64_t)WS_WORKSPACE_BYTES; }
+
+int srk_set_wgrad_workspace(void* workspace, int64_t bytes) {
+  SRK_REQUIRE(bytes >= 0 && (workspace != nullptr || bytes == 0), SRK_E_SHAPE, "set_wgrad_workspace: null pointer with %lld bytes",
+              (long long)bytes);
+  srk_wgrad_bind_workspace(workspace, (size_t)bytes, nullptr, nullptr);
+  return SRK_OK;
 }
 
 int srk_paired_crop_u8(const uint8_t* pool, const int64_t* lr_desc, const int64_t* hr_desc, float* lr_out, float* hr_out, int B,

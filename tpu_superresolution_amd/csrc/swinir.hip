@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "wgrad.h"
 
 namespace {
 
@@ -47,7 +48,7 @@ struct Workspace {
   size_t meanf, rstdf, xnf, fb, t1;
   std::vector<size_t> up;      // pixel-shuffled activations per stage
   // backward
-  size_t gx, gxb, gx2, gxb2, gxbw, du, dxn, dao, dqkv, slab, gyimg, gt1, gfb, gfb32, gstage_w, gstage_side;
+  size_t gx, gxb, gx2, gxb2, gxbw, du, dxn, dao, dqkv, slab, wgpart, gyimg, gt1, gfb, gfb32, gstage_w, gstage_side;
   std::vector<size_t> gup;
   size_t total = 0;
   std::map<std::string, std::pair<size_t, size_t>> names;
@@ -289,6 +290,7 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
     int maxH = 1;
     for (const BlockW& b : p->blocks) maxH = b.nH > maxH ? b.nH : maxH;
     w.slab = a.get("slab", (size_t)srk_attn_bwd_slabs(w.T / 64, 1, nullptr) * maxH * 4096 * 4);
+    w.wgpart = a.get("wgpart", WS_WORKSPACE_BYTES);      // split partials of the streaming weight-gradient kernels
     w.gfb = a.get("gfb", T * CP * 2);
     w.gfb32 = a.get("gfb32", T * CP * 4);
     if (p->cfg.upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
@@ -759,6 +761,14 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
   const bool fuse_ln = CP == 64 || CP == 128 || CP == 192;   // LayerNorm backward inside the dgrad GEMM epilogue (row = one tile)
   float* gstage_w = c.at<float>(w.gstage_w);
   float* gstage_side = c.at<float>(w.gstage_side);
+  // the weight-gradient kernels reduce their row-splits through this region of the caller's workspace; the calling
+  // thread's own registration (srk_set_wgrad_workspace) is restored on every way out
+  struct WgradWorkspaceScope {
+    void* prev_ptr = nullptr;
+    size_t prev_bytes = 0;
+    WgradWorkspaceScope(void* ptr, size_t bytes) { srk_wgrad_bind_workspace(ptr, bytes, &prev_ptr, &prev_bytes); }
+    ~WgradWorkspaceScope() { srk_wgrad_bind_workspace(prev_ptr, prev_bytes, nullptr, nullptr); }
+  } wgrad_scope(c.at<float>(w.wgpart), WS_WORKSPACE_BYTES);
 
   for (int seg = seg_begin; seg < seg_end; ++seg) {
     if (seg == 0) {

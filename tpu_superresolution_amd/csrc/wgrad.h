@@ -29,7 +29,9 @@ struct WgradMulti {
 };
 
 constexpr int WS_SLAB_VEC = 9216;   // accumulator vectors (4 floats) of one workgroup tile: 192 x 192 or 64 x 64 x 9 taps
-float* srk_wgrad_scratch(hipStream_t stream, size_t bytes);
+constexpr size_t WS_WORKSPACE_BYTES = (size_t)256 * WS_SLAB_VEC * 16;   // a launch has at most 256 (tile, split) workgroups
+float* srk_wgrad_scratch(hipStream_t stream, size_t bytes);   // the bound workspace if it is large enough, else null
+void srk_wgrad_bind_workspace(void* ptr, size_t bytes, void** prev_ptr, size_t* prev_bytes);
 void srk_wgrad_partials_enable(int on);
 void srk_wgrad_stream_tune(int rows, int nt);   // rows 32/64 (0 = keep), nt 0/1 (-1 = keep)
 int srk_wgrad_partials_enabled();

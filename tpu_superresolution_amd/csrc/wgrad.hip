@@ -12,10 +12,6 @@
 // The bias gradient comes for free from one extra MFMA column against an all-ones B fragment.
 #include "wgrad.h"
 
-#include <map>
-#include <mutex>
-#include <utility>
-
 namespace {
 
 template <int TA, int TB, bool CONV>
@@ -478,29 +474,21 @@ void srk_wgrad_stream_tune(int rows, int nt) {
 }
 int srk_wgrad_partials_enabled() { return g_wgrad_partials; }
 
-// Scratch for the split partials of the streaming weight-gradient kernels: one buffer per stream (launches on one
-// stream are ordered, so the slabs of one launch are consumed by its reduce kernel before the next launch writes).
-float* srk_wgrad_scratch(hipStream_t stream, size_t bytes) {
-  static std::mutex mu;
-  static std::map<hipStream_t, std::pair<void*, size_t>> pool;
-  std::lock_guard<std::mutex> lock(mu);
-  auto& e = pool[stream];
-  if (e.second < bytes) {
-    if (e.first) {
-      (void)hipStreamSynchronize(stream);
-      (void)hipFree(e.first);
-    }
-    e.first = nullptr;
-    e.second = 0;
-    if (hipMalloc(&e.first, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      e.first = nullptr;
-      return nullptr;
-    }
-    e.second = bytes;
-  }
-  return static_cast<float*>(e.first);
+// Workspace for the split partials of the streaming weight-gradient kernels.  The caller owns it (kernels never
+// allocate): the model executor binds a region of its arena around the backward pass, the stand-alone entry points use
+// what srk_set_wgrad_workspace() registered for the calling thread.  Without a (large enough) workspace the launchers
+// fall back to fp32 atomics straight into dW.
+namespace {
+thread_local float* t_wgrad_ws = nullptr;
+thread_local size_t t_wgrad_ws_bytes = 0;
+}  // namespace
+void srk_wgrad_bind_workspace(void* ptr, size_t bytes, void** prev_ptr, size_t* prev_bytes) {
+  if (prev_ptr) *prev_ptr = t_wgrad_ws;
+  if (prev_bytes) *prev_bytes = t_wgrad_ws_bytes;
+  t_wgrad_ws = static_cast<float*>(ptr);
+  t_wgrad_ws_bytes = ptr ? bytes : 0;
 }
+float* srk_wgrad_scratch(hipStream_t, size_t bytes) { return bytes <= t_wgrad_ws_bytes ? t_wgrad_ws : nullptr; }
 
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
   int rc = validate(p);

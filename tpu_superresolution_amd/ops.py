@@ -139,11 +139,25 @@ def linear_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) 
     return y
 
 
+_WGRAD_WS = {}
+
+
+def _bind_wgrad_workspace(device: torch.device) -> None:
+    """Register this thread's weight-gradient workspace (a cached torch tensor: the caller owns the memory, the library never
+    allocates) so that the stand-alone wgrad entry points reduce their row-splits in a fixed order."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(int(lib().srk_wgrad_workspace_bytes()), dtype=torch.uint8, device=device)
+    check(lib().srk_set_wgrad_workspace(_p(ws), ws.numel()))
+
+
 def linear_wgrad_bf16(y: torch.Tensor, x: torch.Tensor, with_bias: bool = True):
     M, N = y.shape
     K = x.shape[1]
     dw = torch.zeros((N, K), dtype=torch.float32, device=y.device)
     db = torch.zeros((N,), dtype=torch.float32, device=y.device) if with_bias else None
+    _bind_wgrad_workspace(y.device)
     check(lib().srk_linear_wgrad_bf16(_p(y), _p(x), _p(dw), _p(db), M, N, K, _stream()))
     return dw, db
 
@@ -162,6 +176,7 @@ def conv3x3_wgrad_bf16(dy: torch.Tensor, x: torch.Tensor):
     CinP = x.shape[-1]
     dw = torch.zeros((N, 9 * CinP), dtype=torch.float32, device=x.device)
     db = torch.zeros((N,), dtype=torch.float32, device=x.device)
+    _bind_wgrad_workspace(x.device)
     check(lib().srk_conv3x3_wgrad_bf16(_p(dy), _p(x), _p(dw), _p(db), B, H, W, CinP, N, _stream()))
     return dw, db
 
