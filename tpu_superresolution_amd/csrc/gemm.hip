@@ -18,6 +18,11 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK = 64;
 
+#ifndef SRK_GEMM_DMA
+#define SRK_GEMM_DMA 1
+#endif
+__device__ uint4 g_gemm_zero[1];     // 16 zero bytes: DMA source for halo pixels / rows beyond M or N
+
 template <int LD>
 struct RowCtx {  // per-thread staging context for the 4 A passes
   long long base[4];  // element offset of (row, k=0) or conv pixel base
@@ -119,6 +124,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   };
 
+  // LDS-DMA form of load_stage + store_stage: the 16-byte piece a thread used to carry through a VGPR goes straight to its
+  // swizzled LDS position.  A DMA instruction writes lane-linear (lane l -> row l / 8, physical chunk l % 8 of the wave's
+  // eight rows), so the lane fetches the LOGICAL chunk that swz_off() keeps there: schunk ^ (row & 7).  Issued at the top
+  // of step kc for step kc + 1 (the other buffer was last read in step kc - 1, behind that step's barrier); no register
+  // staging, no ds_write pass, and the only wait is vmcnt(0) in front of the step's closing barrier.
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int csrc = schunk ^ (srow & 7);
+  const bf16_t* zero16 = reinterpret_cast<const bf16_t*>(g_gemm_zero);
+  auto issue_stage = [&](int kc, int buf) {
+    const int k0 = kc * BK;
+    const unsigned abase = smem_base + (unsigned)(buf * BM * BK * 2);
+    const unsigned wbase = smem_base + (unsigned)((2 * BM * BK + buf * WS_ROWS * BK) * 2);
+    if constexpr (LD == LD_ROWS) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const bf16_t* src = ctx.yx[ps] ? p.A + ctx.base[ps] + k0 + csrc * 8 : zero16;
+        srk_glds16(src, __builtin_amdgcn_readfirstlane(abase + (unsigned)((wave_u * 8 + 32 * ps) * BK * 2)));
+      }
+    } else {
+      const int tap = k0 / p.CinP;
+      const int ci0 = k0 - tap * p.CinP;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      long long koff;
+      if constexpr (LD == LD_CONV3) {
+        koff = (long long)(dy * p.W + dx) * p.CinP + ci0 + csrc * 8;
+      } else {
+        const int ij = ci0 / p.Cs, cc = ci0 - ij * p.Cs;
+        const int si = ij / p.r, sj = ij - si * p.r;
+        koff = ((long long)(dy * p.r + si) * (p.W * p.r) + (dx * p.r + sj)) * p.Cs + cc + csrc * 8;
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int y = (ctx.yx[ps] >> 16) + dy, x = (ctx.yx[ps] & 0xffff) + dx;
+        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const bf16_t* src = ok ? p.A + ctx.base[ps] + koff : zero16;
+        srk_glds16(src, __builtin_amdgcn_readfirstlane(abase + (unsigned)((wave_u * 8 + 32 * ps) * BK * 2)));
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) {
+      const int n = n0 + srow + 32 * ps;
+      const bf16_t* src = (n < p.N) ? p.Wt + (long long)n * p.K + k0 + csrc * 8 : zero16;
+      srk_glds16(src, __builtin_amdgcn_readfirstlane(wbase + (unsigned)((wave_u * 8 + 32 * ps) * BK * 2)));
+    }
+  };
+
   constexpr int MT = NARROW ? 2 : 4;   // m-tiles (16 rows) per wave
   constexpr int NTT = NARROW ? 1 : NT; // n-tiles per wave
   f32x4_t acc[MT][NTT];
@@ -128,13 +180,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < NTT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
+#if SRK_GEMM_DMA
+  issue_stage(0, 0);
+  srk_wait_vmcnt<0>();
+  srk_lds_barrier();
+#else
   load_stage(0);
   store_stage(0);
   __syncthreads();
+#endif
 
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
+#if SRK_GEMM_DMA
+    if (kc + 1 < nk) issue_stage(kc + 1, buf ^ 1);
+#else
     if (kc + 1 < nk) load_stage(kc + 1);
+#endif
     const bf16_t* a = As + buf * BM * BK;
     const bf16_t* w = Ws + buf * WS_ROWS * BK;
 #pragma unroll
@@ -156,8 +218,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < NTT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
+#if SRK_GEMM_DMA
+    srk_wait_vmcnt<0>();                 // this wave's pieces of the next stage are in LDS ...
+    srk_lds_barrier();                   // ... everyone's are; and every wave is done reading this stage
+#else
     if (kc + 1 < nk) store_stage(buf ^ 1);
     __syncthreads();
+#endif
   }
 
   // ---- row-major epilogue through LDS (everything except the narrow image heads) ----------------
