@@ -157,10 +157,12 @@ int srk_batch_psnr(const float* pred, const float* target, void* workspace, int 
 int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW step (:168-171, :303) on flat fp32 buffers.  The clip coefficient is
  * computed on the device from sumsq[0] (no host sync); grads are first divided by grad_div (world size).
- * max_norm <= 0 disables clipping.  step is the 1-based step count. */
+ * max_norm <= 0 disables clipping.  step is the 1-based step count.  nonfinite: optional DEVICE counter (the one
+ * srk_l1_loss_fwd_bwd fills, :133-143); when it is non-zero, or when the gradient norm itself is NaN/Inf, the call leaves
+ * params and both moments untouched -- the reference raises before backward/step (:159-165), so the weights survive the raise. */
 int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                         const float* sumsq, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, srk_stream_t stream);
+                        float weight_decay, int step, const int32_t* nonfinite, srk_stream_t stream);
 
 /* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
 enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1, SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2 };

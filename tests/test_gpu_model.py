@@ -140,9 +140,18 @@ def test_fused_adamw_matches_oracle_update():
     st = torch.cuda.current_stream().cuda_stream
     check(lib().srk_grad_sumsq(gd.data_ptr(), n, ss.data_ptr(), st))
     check(lib().srk_adamw_clip_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, ss.data_ptr(), 1.0, 2.0, 2e-3,
-                                    0.9, 0.999, 1e-8, 0.01, 3, st))
+                                    0.9, 0.999, 1e-8, 0.01, 3, None, st))
     assert abs(float(ss.sqrt()) / 2.0 - float(total)) <= 1e-4 * float(total)
     assert (pd.cpu() - pr).abs().max() < 2e-6 and (md.cpu() - mr).abs().max() < 1e-6 and (vd.cpu() - vr).abs().max() < 1e-6
+    # a non-zero non-finite counter, or a NaN gradient norm, makes the step a no-op (weights survive for the reference's raise)
+    before = (pd.clone(), md.clone(), vd.clone())
+    bad = torch.ones(1, dtype=torch.int32, device="cuda")
+    check(lib().srk_adamw_clip_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, ss.data_ptr(), 1.0, 2.0, 2e-3,
+                                    0.9, 0.999, 1e-8, 0.01, 4, bad.data_ptr(), st))
+    nan_ss = torch.full((1,), float("nan"), device="cuda")
+    check(lib().srk_adamw_clip_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, nan_ss.data_ptr(), 1.0, 2.0,
+                                    2e-3, 0.9, 0.999, 1e-8, 0.01, 4, None, st))
+    assert torch.equal(pd, before[0]) and torch.equal(md, before[1]) and torch.equal(vd, before[2])
 
 
 def test_train_step_fused_optimizer_moves_like_reference():
@@ -187,3 +196,73 @@ def test_errors_are_loud():
         mm = T.SwinIR(**{**cfg.kwargs(), **bad}).cuda()
         with pytest.raises(NotImplementedError):
             mm(torch.rand(1, 3, 16, 16, device="cuda"))
+
+
+def test_two_live_forwards_raise_instead_of_wrong_gradients():
+    """One activation workspace per engine: backward of an older forward after a newer grad-enabled forward must raise
+    (it would otherwise run on the newer forward's activations and return wrong gradients silently)."""
+    g, cfg, sd = tiny_weights("ps4")
+    m = build(cfg, sd, train=True)
+    x1 = torch.from_numpy(g["x_16x16"]).cuda()
+    x2 = (x1 * 0.5 + 0.1).contiguous()
+    y1 = m(x1)
+    y2 = m(x2)
+    with pytest.raises(RuntimeError, match="overwritten by a later"):
+        (y1.sum() + y2.sum()).backward()
+    # the normal order still works
+    for p in m.parameters():
+        p.grad = None
+    m(x1).sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+
+
+def test_eval_after_torch_optimizer_step_uses_fresh_weights():
+    """train forward/backward, torch.optim.AdamW step (in-place on the flat views), then eval under no_grad: the bf16
+    weight pack must be rebuilt (it used to be one step stale)."""
+    g, cfg, sd = tiny_weights("ps4")
+    x = torch.from_numpy(g["x_16x16"]).cuda()
+    m = build(cfg, sd, train=True)
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-2)
+    with torch.no_grad():
+        m.eval()
+        y0 = m(x).clone()
+        m.train()
+    m(x).abs().mean().backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        y_auto = m(x).clone()
+        m.mark_params_dirty()
+        y_forced = m(x).clone()
+    assert torch.equal(y_auto, y_forced)
+    assert float((y_auto - y0).abs().max()) > 1e-4       # the step really moved the output
+    # the same without any mode switch (in-place edits in eval mode bump the parameters' version counters)
+    with torch.no_grad():
+        opt.step()
+        y_auto = m(x).clone()
+        m.mark_params_dirty()
+        assert torch.equal(y_auto, m(x))
+
+
+def test_nan_batch_leaves_weights_intact():
+    """finetune_swinir.py:159-165 raises on a non-finite output before backward/step; the fused step here is gated on
+    the device-side counter, so the weights and Adam moments survive the bad batch."""
+    from tpu_superresolution_amd.optim import FusedAdamW
+    from tpu_superresolution_amd.training import assert_finite_step, train_step
+    g, cfg, sd = tiny_weights("ps4")
+    m = build(cfg, sd, train=True)
+    opt = FusedAdamW(m, lr=1e-2, weight_decay=0.0, max_grad_norm=1.0)
+    x = torch.from_numpy(g["x_16x16"]).cuda()
+    hr = torch.rand(x.shape[0], 3, 64, 64, device="cuda")
+    train_step(m, opt, x, hr)                                   # a good step first (moments non-zero)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    mom = (opt._m.clone(), opt._v.clone())
+    xb = x.clone()
+    xb[0, 0, 0, 0] = float("nan")
+    loss, bad = train_step(m, opt, xb, hr)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        assert_finite_step(loss, bad)
+    after = m.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    assert torch.equal(mom[0], opt._m) and torch.equal(mom[1], opt._v)
+    assert all(bool(torch.isfinite(v).all()) for v in after.values() if v.dtype.is_floating_point)

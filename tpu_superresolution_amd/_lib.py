@@ -71,7 +71,7 @@ _SIGNATURES = {
     "srk_batch_psnr_workspace": (_i64, [_i64, _i]),
     "srk_batch_psnr": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
     "srk_grad_sumsq": (_i, [_vp, _i64, _vp, _vp]),
-    "srk_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    "srk_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "srk_swinir_plan_create": (_i, [C.POINTER(SwinIRConfig), C.POINTER(_vp)]),
     "srk_swinir_plan_destroy": (None, [_vp]),
     "srk_swinir_param_floats": (_i64, [_vp]),
@@ -112,6 +112,20 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+_claimed_device = None
+
+
+def claim_device(index: int) -> None:
+    """libsrk keeps per-process device state (CU count, per-kernel LDS limits configured once): ONE GPU per process -- the
+    data-parallel design is one process per GPU anyway.  The first engine claims its device; another device raises."""
+    global _claimed_device
+    if _claimed_device is None:
+        _claimed_device = int(index)
+    elif _claimed_device != int(index):
+        raise RuntimeError(f"libsrk is bound to cuda:{_claimed_device} in this process (one GPU per process); "
+                           f"cannot also drive cuda:{index} -- start one process per GPU")
 
 
 def check(rc: int) -> None:

@@ -358,11 +358,11 @@ int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t str
 
 int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sumsq,
                         float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float weight_decay,
-                        int step, srk_stream_t stream) {
+                        int step, const int32_t* nonfinite, srk_stream_t stream) {
   REQ_PTR(params); REQ_PTR(grads); REQ_PTR(exp_avg); REQ_PTR(exp_avg_sq);
   SRK_REQUIRE(max_norm <= 0.f || sumsq != nullptr, SRK_E_NULL, "adamw: clipping needs sumsq");
   SRK_REQUIRE(step >= 1 && grad_div > 0.f, SRK_E_SHAPE, "adamw: step=%d grad_div=%f", step, grad_div);
-  return srk_launch_adamw(params, grads, exp_avg, exp_avg_sq, n, sumsq, max_norm, grad_div, lr, beta1, beta2, eps,
+  return srk_launch_adamw(params, grads, exp_avg, exp_avg_sq, n, sumsq, nonfinite, max_norm, grad_div, lr, beta1, beta2, eps,
                           weight_decay, step, (hipStream_t)stream);
 }
 

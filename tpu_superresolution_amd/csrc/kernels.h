@@ -46,5 +46,5 @@ int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStre
 int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream);
 int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, float* loss_sum, unsigned* nonfinite, long long n, float grad_scale, hipStream_t stream);
 int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream);
-int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t stream);
+int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, const int* nonfinite, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t stream);
 int srk_launch_probe_trread(const bf16_t* in, bf16_t* out, hipStream_t stream);

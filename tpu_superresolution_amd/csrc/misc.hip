@@ -643,12 +643,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
                                                     const float* __restrict__ sumsq, float max_norm, float grad_div,
                                                     float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt) {
+                                                    float bc2_sqrt, const int* __restrict__ nonfinite) {
+  // a non-finite forward (counter of the loss kernel) or a non-finite gradient norm leaves weights and moments untouched:
+  // the reference raises before backward/step (finetune_swinir.py:159-165), so the model must survive for that raise
+  if (nonfinite != nullptr && *nonfinite != 0) return;
   float coef = 1.0f / grad_div;
-  if (max_norm > 0.f) {
-    const float total = sqrtf(*sumsq) / grad_div;
-    const float c = max_norm / (total + 1e-6f);
-    coef *= c < 1.0f ? c : 1.0f;
+  if (sumsq != nullptr) {
+    const float ss = *sumsq;
+    if (!(ss == ss) || ss > 3.0e38f) return;
+    if (max_norm > 0.f) {
+      const float total = sqrtf(ss) / grad_div;
+      const float c = max_norm / (total + 1e-6f);
+      coef *= c < 1.0f ? c : 1.0f;
+    }
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
@@ -875,13 +882,13 @@ int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream
   return srk_check_launch("sumsq");
 }
 
-int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, float max_norm,
+int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, const int* nonfinite, float max_norm,
                      float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step,
                      hipStream_t stream) {
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, sumsq, max_norm,
-                     grad_div, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
+                     grad_div, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), nonfinite);
   return srk_check_launch("adamw");
 }
 

@@ -14,8 +14,8 @@ from . import _lib
 from ._lib import SwinIRConfig, check, lib
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class ParamInfo:
@@ -90,16 +90,25 @@ class SwinIREngine:
     """Device state for one model replica on one GPU."""
 
     def __init__(self, plan: SwinIRPlan, device: torch.device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("SwinIR HIP path needs a GPU device; there is no CPU fallback in this package")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        _lib.claim_device(device.index)
         self.plan = plan
         self.device = device
         self.flat = torch.zeros(plan.param_floats, dtype=torch.float32, device=device)
         self.flat_grad: Optional[torch.Tensor] = None
         self.const = torch.empty(max(1, lib().srk_swinir_const_bytes(plan.handle)), dtype=torch.uint8, device=device)
-        check(lib().srk_swinir_const_init(plan.handle, self.const.data_ptr(), _stream()))
+        with torch.cuda.device(device):
+            check(lib().srk_swinir_const_init(plan.handle, self.const.data_ptr(), _stream(device)))
         self.packed = torch.empty(lib().srk_swinir_packed_bytes(plan.handle), dtype=torch.uint8, device=device)
         self.workspace: Optional[torch.Tensor] = None
         self._ws_key = None
         self.packed_valid = False
+        self.pack_version = -1            # sum of the parameters' autograd version counters at the last pack
+        self.generation = 0               # bumped by every training forward: ties an autograd node to "its" workspace
         self.segment_hook: Optional[Callable[[int, int, int], None]] = None
 
     # -- parameters -------------------------------------------------------------------------------
@@ -107,7 +116,8 @@ class SwinIREngine:
         return {p.name: base[p.offset:p.offset + p.numel].view(p.shape) for p in self.plan.params}
 
     def pack(self) -> None:
-        check(lib().srk_swinir_pack(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), _stream()))
+        with torch.cuda.device(self.device):
+            check(lib().srk_swinir_pack(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), _stream(self.device)))
         self.packed_valid = True
 
     def ensure_grad(self) -> torch.Tensor:
@@ -128,6 +138,8 @@ class SwinIREngine:
     def forward(self, x: torch.Tensor, training: bool, drop_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("SwinIR HIP path needs a GPU tensor; there is no CPU fallback in this package")
+        if x.device != self.device:
+            raise RuntimeError(f"input is on {x.device} but the model is bound to {self.device}")
         x = x.contiguous().float()
         B, Cin, H, W = x.shape
         if Cin != self.plan.cfg.in_chans:
@@ -138,8 +150,11 @@ class SwinIREngine:
         s = self.plan.upscale
         y = torch.empty((B, Cin, H * s, W * s), dtype=torch.float32, device=self.device)
         ds = drop_scale.contiguous().data_ptr() if drop_scale is not None else None
-        check(lib().srk_swinir_forward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), x.data_ptr(), y.data_ptr(),
-                                       ws.data_ptr(), B, H, W, int(training), ds, _stream()))
+        if training:
+            self.generation += 1
+        with torch.cuda.device(self.device):      # kernels launch on the current device: make it the tensors' device
+            check(lib().srk_swinir_forward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), x.data_ptr(),
+                                           y.data_ptr(), ws.data_ptr(), B, H, W, int(training), ds, _stream(self.device)))
         return y
 
     def backward(self, d_y: torch.Tensor, shape: Tuple[int, int, int], drop_scale: Optional[torch.Tensor] = None) -> None:
@@ -150,12 +165,14 @@ class SwinIREngine:
         g = self.ensure_grad()
         d_y = d_y.contiguous().float()
         ds = drop_scale.contiguous().data_ptr() if drop_scale is not None else None
-        for seg in range(self.plan.num_segments):
-            check(lib().srk_swinir_backward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), g.data_ptr(),
-                                            d_y.data_ptr(), self.workspace.data_ptr(), B, H, W, ds, seg, seg + 1, _stream()))
-            if self.segment_hook is not None:
-                b, e = self.plan.segment_ranges[seg]
-                self.segment_hook(seg, b, e)
+        with torch.cuda.device(self.device):
+            for seg in range(self.plan.num_segments):
+                check(lib().srk_swinir_backward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), g.data_ptr(),
+                                                d_y.data_ptr(), self.workspace.data_ptr(), B, H, W, ds, seg, seg + 1,
+                                                _stream(self.device)))
+                if self.segment_hook is not None:
+                    b, e = self.plan.segment_ranges[seg]
+                    self.segment_hook(seg, b, e)
 
     def activation(self, name: str, dtype: torch.dtype) -> torch.Tensor:
         """Debug/parity view of a named workspace buffer (flat)."""
@@ -176,6 +193,7 @@ class _SwinIRFunction(torch.autograd.Function):
         ctx.shape = (x.shape[0], x.shape[2], x.shape[3])
         ctx.drop_scale = drop_scale
         ctx.trained = training
+        ctx.generation = eng.generation
         return y
 
     @staticmethod
@@ -183,5 +201,11 @@ class _SwinIRFunction(torch.autograd.Function):
         module = ctx.module
         if not ctx.trained:
             raise RuntimeError("SwinIR forward was run without gradient tracking")
+        eng = module._engine
+        if eng is None or ctx.generation != eng.generation:
+            # one activation workspace per engine: a later grad-enabled forward has overwritten what this node saved
+            raise RuntimeError("SwinIR.backward: the saved activations of this forward were overwritten by a later "
+                               "grad-enabled forward of the same model; call backward() before the next training forward "
+                               "(one live autograd graph per model)")
         module._backward_into_flat(d_y, ctx.shape, ctx.drop_scale)
         return None, None, None, None, None

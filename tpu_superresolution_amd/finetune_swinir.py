@@ -200,7 +200,11 @@ def main(argv=None):
         print(f"[params] trainable tensors: {n_train} / total: {len(list(model.parameters()))}")
 
     dp = DataParallelSwinIR(model)
-    dp.attach(device)
+    dp.attach(device)                 # weights are now identical on every rank (broadcast from rank 0)
+    if world > 1:
+        # per-rank randomness from here on: DropPath masks and crop corners must differ between ranks, or stochastic
+        # depth / crop diversity would not scale with the world size (bench.py seeds 1234 + rank the same way)
+        seed_everything(args.seed + rank)
     opt = FusedAdamW(model, lr=args.lr, weight_decay=args.weight_decay,
                      max_grad_norm=args.grad_clip if args.grad_clip and args.grad_clip > 0 else None, grad_div=float(world))
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.epochs, eta_min=args.min_lr) if args.scheduler == "Cosine" else None

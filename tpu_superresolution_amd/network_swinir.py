@@ -305,6 +305,11 @@ class SwinIR(nn.Module):
         if getattr(self, "_engine", None) is not None:
             self._engine.packed_valid = False
 
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            self.mark_params_dirty()      # a train -> eval switch usually follows optimizer steps
+        return super().train(mode)
+
     def _apply(self, fn, *args, **kwargs):
         self._engine = None        # .to()/.cuda()/.float() re-create the parameter tensors: re-bind lazily
         return super()._apply(fn, *args, **kwargs)
@@ -398,6 +403,15 @@ class SwinIR(nn.Module):
         needs_grad = torch.is_grad_enabled() and anchor is not None
         if self.training or needs_grad:
             eng.packed_valid = False          # parameters may have been stepped since the last call
+            eng.pack_version = -1
+        else:
+            # inference reuses the bf16 pack only while no parameter has been written in place since it was made
+            # (torch.optim.* steps, p.mul_(), ... bump the autograd version counter; FusedAdamW / load_state_dict /
+            # mark_params_dirty / train()<->eval() switches clear packed_valid themselves)
+            ver = sum(p._version for p in self.parameters())
+            if ver != eng.pack_version:
+                eng.packed_valid = False
+                eng.pack_version = ver
         if drop_scale is None:
             drop_scale = self._drop_scale(x.shape[0], x.device)
         if needs_grad:

@@ -24,6 +24,10 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
         return None
     if not t.is_cuda:
         raise RuntimeError("libsrk operates on GPU tensors only (got a CPU tensor); there is no CPU fallback")
+    if t.device.index != torch.cuda.current_device():
+        # the kernel would launch on the current device with another device's pointers (a GPU fault, not a Python error)
+        raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "libsrk ops launch on the current device (torch.cuda.set_device / one process per GPU)")
     if not t.is_contiguous():
         raise RuntimeError("libsrk needs contiguous tensors")
     return t.data_ptr()

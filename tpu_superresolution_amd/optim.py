@@ -16,8 +16,8 @@ from ._lib import check, lib
 from .network_swinir import SwinIR
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -64,30 +64,40 @@ class FusedAdamW(torch.optim.Optimizer):
         """Global L2 norm of the (averaged) gradients as a device tensor (no host sync)."""
         eng = self._prepare()
         g = eng.ensure_grad()
-        self._sumsq.zero_()
-        for b, e in self._ranges:
-            check(lib().srk_grad_sumsq(g.data_ptr() + 4 * b, e - b, self._sumsq.data_ptr(), _stream()))
-        return self._sumsq.sqrt() / self.grad_div
+        with torch.cuda.device(eng.device):
+            self._sumsq.zero_()
+            for b, e in self._ranges:
+                check(lib().srk_grad_sumsq(g.data_ptr() + 4 * b, e - b, self._sumsq.data_ptr(), _stream(eng.device)))
+            return self._sumsq.sqrt() / self.grad_div
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, nonfinite: Optional[torch.Tensor] = None):
+        """clip + AdamW.  `nonfinite`: optional int32 device counter (training.l1_loss_checked); when it is non-zero -- or
+        when the gradient norm is NaN/Inf -- the kernels leave weights and moments untouched (no host sync needed), so a
+        bad batch cannot destroy the model before the caller's finite check raises (finetune_swinir.py:159-165)."""
         if closure is not None:
             raise RuntimeError("FusedAdamW does not support closures")
         eng = self._prepare()
         g = eng.ensure_grad()
         grp = self.param_groups[0]
         clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
-        if clip > 0:
-            self._sumsq.zero_()
+        bad = None
+        if nonfinite is not None:
+            if nonfinite.dtype != torch.int32 or nonfinite.device != eng.flat.device:
+                raise ValueError("nonfinite must be an int32 tensor on the model's device")
+            bad = nonfinite.data_ptr()
+        with torch.cuda.device(eng.device):
+            st = _stream(eng.device)
+            self._sumsq.zero_()          # always computed: a NaN/Inf norm gates the step even without clipping
             for b, e in self._ranges:
-                check(lib().srk_grad_sumsq(g.data_ptr() + 4 * b, e - b, self._sumsq.data_ptr(), _stream()))
-        self._step += 1
-        b1, b2 = grp["betas"]
-        for b, e in self._ranges:
-            check(lib().srk_adamw_clip_step(eng.flat.data_ptr() + 4 * b, g.data_ptr() + 4 * b, self._m.data_ptr() + 4 * b,
-                                            self._v.data_ptr() + 4 * b, e - b, self._sumsq.data_ptr(), float(clip),
-                                            self.grad_div, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
-                                            float(grp["weight_decay"]), self._step, _stream()))
+                check(lib().srk_grad_sumsq(g.data_ptr() + 4 * b, e - b, self._sumsq.data_ptr(), st))
+            self._step += 1
+            b1, b2 = grp["betas"]
+            for b, e in self._ranges:
+                check(lib().srk_adamw_clip_step(eng.flat.data_ptr() + 4 * b, g.data_ptr() + 4 * b, self._m.data_ptr() + 4 * b,
+                                                self._v.data_ptr() + 4 * b, e - b, self._sumsq.data_ptr(), float(clip),
+                                                self.grad_div, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                                float(grp["weight_decay"]), self._step, bad, st))
         eng.packed_valid = False
         return None
 

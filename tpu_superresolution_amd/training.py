@@ -44,7 +44,10 @@ def train_step(model, optimizer, lr_img: torch.Tensor, hr_img: torch.Tensor, syn
     loss.backward()
     if sync is not None:
         sync.finish()
-    optimizer.step()
+    if hasattr(optimizer, "max_grad_norm"):      # FusedAdamW: the device-side counter gates the update (no host sync)
+        optimizer.step(nonfinite=bad)
+    else:
+        optimizer.step()
     return loss.detach(), bad
 
 
