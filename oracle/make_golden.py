@@ -48,9 +48,57 @@ def build_ref_model(ns, cfg: O.SwinIRConfig, sd):
     return m.eval()
 
 
+def schema_digest(sd) -> str:
+    return hashlib.sha1("\n".join(f"{k}:{tuple(v.shape)}:{v.dtype}" for k, v in sd.items()).encode()).hexdigest()
+
+
+def gen_g11():
+    """G11: MS_ResUNet (ms_resunet.py imports directly: torch + numpy only).  Weights from oracle.cfg1_weights (seed only is
+    stored); eval forward on [1,1,128,128] (BASELINE cfg1) and on an odd size (exercises _crop_like), and one train-mode
+    forward/backward (BatchNorm batch statistics) on [2,1,32,32]."""
+    from oracle.cfg1_weights import fill_state_dict
+    ms = import_reference("ms_resunet")
+    torch.manual_seed(0)
+    m = ms.MS_ResUNet()
+    n_params = sum(p.numel() for p in m.parameters())
+    sd = fill_state_dict(m.state_dict(), seed=11)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    arrays = dict(n_params=np.array(n_params), n_keys=np.array(len(sd)), schema_sha1=np.array(schema_digest(m.state_dict())),
+                  weight_seed=np.array(11))
+    m.eval()
+    for tag, shape, seed in (("128", (1, 1, 128, 128), 0), ("odd", (1, 1, 50, 37), 1)):
+        x = torch.rand(*shape, generator=torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            y = m(x).numpy()
+        assert y.shape == shape
+        pg = np.random.RandomState(2).randint(0, y.size, size=64)
+        arrays.update({f"{tag}.input_seed": np.array(seed), f"{tag}.shape": np.array(shape), f"{tag}.probe_index": pg,
+                       f"{tag}.probe_value": y.reshape(-1)[pg], f"{tag}.mean": np.array(y.mean()), f"{tag}.std": np.array(y.std()),
+                       f"{tag}.sha1": np.array(sha1(y))})
+        print("G11", tag, "mean", y.mean(), "std", y.std())
+    m.train()
+    x = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(3))
+    t = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(4))
+    loss = torch.nn.functional.mse_loss(m(x), t)
+    loss.backward()
+    names = ["conv1.weight", "layer2.0.downsample.0.weight", "layer4.2.bn3.weight", "mflow_conv_g1_pool.0.3_outvar_dimred.weight",
+             "adapt_stage3_b.0.2_conv.bias", "upCT3.weight", "clf_conv2.weight"]
+    named = dict(m.named_parameters())
+    arrays["train.loss"] = np.array(float(loss))
+    arrays["train.grad_names"] = np.array(names)
+    arrays["train.grad_norms"] = np.array([float(named[n].grad.norm()) for n in names])
+    arrays["train.running_mean_bn1"] = m.bn1.running_mean.detach().numpy().copy()
+    print("G11 train loss", float(loss), "params", n_params, "keys", len(sd))
+    save("g11_ms_resunet", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-g11" in sys.argv:
+        return gen_g11()
+    gen_g11()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------
