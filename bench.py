@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """Headline benchmark: SwinIR classical x4 TRAIN STEP, 64x64 LR patches, batch 32 per GPU (BASELINE cfg3).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                 (N > 1 without WORLD_SIZE: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --config cfg2                                 (SwinIR-light x2 inference, 48x48 LR, bs 16: BASELINE cfg2)
 
 A step = forward + L1 loss + backward + (N>1: RCCL gradient all-reduce, overlapped) + clip 1.0 + AdamW on
 one batch of synthetic LR/HR patches already resident in HBM.  Prints ONE JSON line on rank 0.
 Weak scaling: every rank processes its own 32 patches.
+
+The JSON line's `roofline` has the dominant kernel family (HIP events inside the timed region) and `roofline.step`: the
+whole step against the MFMA roofline (SURVEY 8d's primary bound) plus HBM bytes per step -- measured (rocprofv3 PMC summary
+under profiles/, used only while its kernel-source digest matches the library being run) vs the block-fused compulsory
+bytes of SURVEY 8d.
 
 Extra legs (rank 0, N=1):
   roofline     -- HIP-event timing of the dominant kernel family (the linear-layer MFMA GEMM) bracketed
@@ -69,16 +75,198 @@ def cpu_baseline(steps=3, batch=2, threads=None):
             "sample": f"{steps} fp32 train steps of the CPU oracle at batch {batch} (median {med:.2f} s/step), same model/loss/optimizer"}
 
 
+
+def kernels_digest():
+    """sha1 over the kernel sources: ties a stored PMC summary to the library it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "tpu_superresolution_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stored_traffic(name):
+    """-> (value or None, source dict).  A stored rocprofv3 PMC figure is reported only while the kernel sources are the
+    ones it was measured on; otherwise the value is withheld (null) and the line says so."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    fresh = d.get("kernels_sha") == kernels_digest()
+    src = {"file": "profiles/" + name, "kernels_sha": d.get("kernels_sha"), "matches_this_library": fresh,
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, (2*FETCH+WRITE)*1024 (MI355X_MICROARCH.md)"}
+    return d, src
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started by hand: become the launcher.  Runs BEFORE anything touches the GPU (no HIP call, no
+    torch.cuda.is_available()); the ranks are ordinary child processes (no exec), rank 0's stdout is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+# SURVEY 8d: compulsory HBM bytes of a block-fused executor, forward, fp32 residual stream: 301 MB per 64x64 LR image;
+# training ~3.25x forward (saved block inputs re-read, dY read, dX written); + 333 MB optimizer traffic per step.
+COMPULSORY_FWD_BYTES_PER_IMAGE = 301e6
+COMPULSORY_TRAIN_FACTOR = 3.25
+OPTIMIZER_BYTES_PER_STEP = 11_900_199 * 28
+
+
+def bench_cfg2(args):
+    """BASELINE cfg2: SwinIR-light x2 (dim 60, 4x6 blocks, window 8, pixelshuffledirect) inference, 48x48 LR, bs 16.
+    A step = one forward of one batch resident in HBM.  Replicas only for N > 1 (no collective)."""
+    import torch.distributed as dist
+    import tpu_superresolution_amd as T
+    from tpu_superresolution_amd import _lib
+    from tpu_superresolution_amd.distributed import init_from_env
+    rank, world, local = init_from_env("nccl") if args.gpus > 1 else (0, 1, 0)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.manual_seed(42)
+    model = T.SwinIR(upscale=2, in_chans=3, img_size=64, window_size=8, img_range=1.0, depths=[6] * 4, embed_dim=60,
+                     num_heads=[6] * 4, mlp_ratio=2, upsampler="pixelshuffledirect").to(device).eval()
+    bs = args.batch or 16
+    x = torch.rand(bs, 3, 48, 48, generator=torch.Generator().manual_seed(rank)).to(device)
+    flop_per_image = 4.818e9                    # SURVEY 6 / 8d (FlopCounterMode on the reference)
+    lib = _lib.lib()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 2)):
+            y = model(x)
+        graph = None
+        if not args.no_graph:
+            # ~150 small launches per forward: replay them as one hipGraph (the eager loop is launch-bound)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(x)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                y = model(x)
+            graph.replay()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                y = model(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        roof = None
+        if rank == 0 and not args.no_roofline:      # un-timed extra pass with every GEMM launch bracketed (eager: events
+            _lib.check(lib.srk_set_option(b"probe_stride", 1))       # cannot be recorded inside a captured graph)
+            _lib.check(lib.srk_probe_begin(1, 4000))
+            for _ in range(5):
+                model(x)
+            torch.cuda.synchronize()
+            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            _lib.check(lib.srk_probe_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
+            if n.value:
+                gbs, tfl = by.value / (ms.value * 1e-3) / 1e9, fl.value / (ms.value * 1e-3) / 1e12
+                roof = {"bound": "hbm", "kernel": "linear-layer GEMMs of the light model (gemm_kernel / gemm_stream*, csrc/gemm*.hip)",
+                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value,
+                        "avg_launch_us": 1e3 * ms.value / n.value,
+                        "mfma": {"achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS}}
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    if not bool(torch.isfinite(y).all()):
+        raise SystemExit("non-finite output during the benchmark")
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * bs * 96 * 96 * args.steps / elapsed
+        tfl_step = bs * flop_per_image / (ms_per_step * 1e-3) / 1e12
+        out = {"metric": "HR pixels/sec, SwinIR-light x2 inference, 48x48 LR, bs=16/GPU", "value": value, "unit": "HR pixels/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE cfg2: SwinIR-light x2 (dim 60, 4x6 blocks, window 8, pixelshuffledirect) inference "
+                                      "forward, 48x48 LR -> 96x96 HR, random-init weights", "batch_per_gpu": bs,
+                          "global_batch": bs * world, "parallelism": f"replicas{world}", "hip_graph": graph is not None,
+                          "per_gpu_value": value / world, "step_tflops_per_gpu": tfl_step}}
+        if roof is not None:
+            roof["step"] = {"mfma_frac": tfl_step / MFMA_BF16_PEAK_TFLOPS, "algorithmic_tflop_per_step": bs * flop_per_image / 1e12}
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_cfg2()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_cfg2(steps=3, batch=16):
+    from oracle import swinir_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = int(os.environ.get("SRK_CPU_BASELINE_THREADS", max(1, min(avail, 32))))
+    torch.set_num_threads(threads)
+    cfg = O.SwinIRConfig.light_x2()
+    sd = O.random_state_dict(cfg, 42, 1.0)
+    x = torch.rand(batch, 3, 48, 48, generator=torch.Generator().manual_seed(0))
+    times = []
+    with torch.no_grad():
+        O.swinir_forward(sd, cfg, x)
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            O.swinir_forward(sd, cfg, x)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": batch * 96 * 96 / med, "unit": "HR pixels/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} fp32 forwards of the CPU oracle at batch {batch} (median {med:.2f} s), same model"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU (BASELINE: 32)")
+    ap.add_argument("--config", choices=["cfg3", "cfg2"], default="cfg3",
+                    help="cfg3 (default): the headline train step; cfg2: SwinIR-light x2 inference")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (BASELINE: 32 for cfg3, 16 for cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
     args = ap.parse_args()
-
+    if args.steps is None:
+        args.steps = 20 if args.config == "cfg3" else 200
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])           # never returns
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.config == "cfg2":
+        return bench_cfg2(args)
+    args.batch = args.batch or 32
     import torch.distributed as dist
     import tpu_superresolution_amd as T
     from tpu_superresolution_amd import _lib
@@ -89,8 +277,6 @@ def main():
     rank, world, local = init_from_env("nccl") if args.gpus > 1 else (0, 1, 0)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -135,14 +321,13 @@ def main():
             # MI355X ridge (~310 FLOP/B), so with one launch per layer the family is HBM-bound, not MFMA-bound.
             gbs = by.value / (ms.value * 1e-3) / 1e9
             tfl = fl.value / (ms.value * 1e-3) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_pmc_linear_gemm_stream_traffic.json")
-            if os.path.exists(tf):
-                traffic = json.load(open(tf))["avg_hbm_bytes_per_launch"]      # rocprofv3 PMC, same workload
+            fam, fam_src = stored_traffic("r02_pmc_linear_gemm_stream_traffic.json")
+            traffic = fam["avg_hbm_bytes_per_launch"] if fam and fam_src["matches_this_library"] else None
             roof = {"bound": "hbm", "kernel": "gemm_stream_kernel / gemm_stream_split_kernel (csrc/gemm_stream.hip: persistent LDS-DMA "
                                                "GEMM of the linear layers -- proj/fc1/fc2 forward and the qkv/proj/fc1/fc2 dgrads with their "
                                                "fused bias/GELU/residual/LayerNorm epilogues; the qkv forward lives in attn_fused.hip)",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": fam_src,
                     "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value, "sampled_every": PROBE_STRIDE,
                     "avg_launch_us": 1e3 * ms.value / n.value, "share_of_step": PROBE_STRIDE * ms.value / (1e3 * elapsed),
                     "mfma": {"achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS}}
@@ -167,6 +352,15 @@ def main():
                           "step_tflops_per_gpu": args.batch * FLOP_PER_IMAGE_TRAIN / (ms_per_step * 1e-3) / 1e12,
                           "final_loss": float(loss)}}
         if roof is not None:
+            # whole step against the MFMA roofline (SURVEY 8d's primary bound) and its HBM bytes against the compulsory bytes
+            comp = args.batch * COMPULSORY_FWD_BYTES_PER_IMAGE * COMPULSORY_TRAIN_FACTOR + OPTIMIZER_BYTES_PER_STEP
+            st, st_src = stored_traffic("r02_pmc_step_traffic.json")
+            hbm_step = st["hbm_bytes_per_step"] if st and st_src["matches_this_library"] and args.batch == 32 else None
+            roof["step"] = {"mfma_frac": out["config"]["step_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS,
+                            "algorithmic_tflop_per_step": args.batch * FLOP_PER_IMAGE_TRAIN / 1e12,
+                            "hbm_bytes_per_step": hbm_step, "hbm_bytes_source": st_src,
+                            "compulsory_bytes_per_step": comp,
+                            "traffic_ratio": (hbm_step / comp) if hbm_step else None}
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

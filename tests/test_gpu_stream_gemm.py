@@ -39,9 +39,11 @@ def test_stream_linear_bf16_vs_torch(ops, M, N, K):
     set_stream(1)
     y = ops.linear_bf16(dev(a), dev(w), dev(b))
     close_bf16(y, ref, 2e-3)
-    set_stream(0)
-    y0 = ops.linear_bf16(dev(a), dev(w), dev(b))
-    set_stream(1)
+    try:
+        set_stream(0)
+        y0 = ops.linear_bf16(dev(a), dev(w), dev(b))
+    finally:
+        set_stream(1)
     close_bf16(y0, ref, 2e-3)
     # identical bf16 results except where the fp32 sums straddle a rounding boundary
     assert float((y.float() != y0.float()).float().mean()) < 2e-3
@@ -78,15 +80,17 @@ def test_stream_and_tile_paths_agree_on_a_cfg3_width_model(drop):
         keep = 1.0 - torch.linspace(0, 0.3, 4).view(4, 1, 1)
         ds = ((torch.rand(4, 2, 4, generator=gen) < keep).float() / keep).cuda()
     res = {}
-    for on in (1, 0):
-        set_stream(on)
-        m = build(cfg, sd, train=True, drop_path_rate=0.3 if drop else 0.0)
-        out = m(x, drop_scale=ds)
-        loss = torch.nn.functional.l1_loss(out, t)
-        loss.backward()
-        torch.cuda.synchronize()
-        res[on] = (out.detach().cpu(), float(loss), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
-    set_stream(1)
+    try:
+        for on in (1, 0):
+            set_stream(on)
+            m = build(cfg, sd, train=True, drop_path_rate=0.3 if drop else 0.0)
+            out = m(x, drop_scale=ds)
+            loss = torch.nn.functional.l1_loss(out, t)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[on] = (out.detach().cpu(), float(loss), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
+    finally:
+        set_stream(1)
     out1, l1, g1 = res[1]
     out0, l0, g0 = res[0]
     assert torch.isfinite(out1).all()
@@ -97,6 +101,46 @@ def test_stream_and_tile_paths_agree_on_a_cfg3_width_model(drop):
     print(f"drop={drop}: out diff {float((out1 - out0).abs().max()):.3e}, grad rel-L2 median {np.median(list(rels.values())):.3e}, worst {rels[worst]:.3e} ({worst})")
     assert rels[worst] <= 2e-2, f"{worst}: {rels[worst]:.3e}"
     assert float(np.median(list(rels.values()))) <= 4e-3
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_streaming_path_forward_and_gradients_vs_oracle_and_emulation(drop):
+    """Direct oracle contact for the persistent kernels at the cfg3 width: embed 180 / 6 heads /
+    hidden 360, bs 4 at 64x64 -> M = 16 384 rows, where the streaming GEMMs (incl. the K = 384 / 576 fused
+    LayerNorm-backward epilogues), the fused qkv + attention kernel and the ring weight-gradient kernel are the ones that
+    run.  Forward, loss and every parameter gradient against the fp32 oracle (bf16-noise tolerances of test_gpu_model.py)
+    and against the bf16-rounding emulation (tolerances of test_gpu_emulation.py, ~5x tighter)."""
+    from oracle import bf16_emulation as E
+    cfg = _mid_cfg()
+    sd = O.random_state_dict(cfg, seed=7, scale=1.0)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(4, 3, 64, 64, generator=gen)
+    t = torch.rand(4, 3, 128, 128, generator=gen)
+    ds = None
+    if drop:
+        keep = 1.0 - torch.linspace(0, 0.3, 4).view(4, 1, 1)
+        ds = (torch.rand(4, 2, 4, generator=gen) < keep).float() / keep
+        ds[1, 0, 0] = 0.0
+    set_stream(1)
+    m = build(cfg, sd, train=True, drop_path_rate=0.3 if drop else 0.0)
+    out = m(x.cuda(), drop_scale=None if ds is None else ds.cuda())
+    loss = torch.nn.functional.l1_loss(out, t.cuda())
+    loss.backward()
+    out = out.detach().cpu()
+    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    for name, (fn, fwd_tol, loss_tol, g_tol, g_med) in {"oracle": (O.loss_and_grads, 1.2e-2, 2e-3, 0.1, 0.04),
+                                                      "emulation": (E.loss_and_grads_emul, 6e-3, 1e-3, 5e-2, 1e-2)}.items():
+        loss_r, out_r, grads_r = fn(sd, cfg, x, t, drop_keep=ds)
+        err = float((out - out_r).abs().max())
+        rels = {n: float((grads[n] - grads_r[n]).norm() / (grads_r[n].norm() + 1e-12)) for n in grads_r}
+        worst = max(rels, key=rels.get)
+        print(f"[{name}] drop={drop}: fwd err {err:.3e} (max|ref| {float(out_r.abs().max()):.3f}), loss rel "
+              f"{abs(float(loss) - float(loss_r)) / float(loss_r):.2e}, grad rel-L2 median {np.median(list(rels.values())):.3e}, "
+              f"worst {rels[worst]:.3e} ({worst})")
+        assert err <= fwd_tol * float(out_r.abs().max()), name
+        assert abs(float(loss) - float(loss_r)) <= loss_tol * float(loss_r), name
+        assert rels[worst] <= g_tol, f"{name}: {worst}: {rels[worst]:.3e}"
+        assert float(np.median(list(rels.values()))) <= g_med, name
 
 
 @pytest.mark.parametrize("upsampler", ["pixelshuffle", "pixelshuffledirect"])
@@ -110,13 +154,15 @@ def test_all_taps_conv_wgrad_matches_per_tap_tiles_on_the_model(upsampler):
     x = torch.rand(4, 3, 64, 64, generator=gen).cuda()
     t = torch.rand(4, 3, 128, 128, generator=gen).cuda()
     res = {}
-    for on in (2, 1, 0):          # 2: all-taps LDS-DMA ring (default), 1: all-taps register-staged, 0: per-tap tiles / VALU head
-        check(lib().srk_set_option(b"conv_wgrad_taps", on))
-        m = build(cfg, sd, train=True)
-        torch.nn.functional.l1_loss(m(x), t).backward()
-        torch.cuda.synchronize()
-        res[on] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
-    check(lib().srk_set_option(b"conv_wgrad_taps", 2))
+    try:
+        for on in (2, 1, 0):      # 2: all-taps LDS-DMA ring (default), 1: all-taps register-staged, 0: per-tap tiles / VALU head
+            check(lib().srk_set_option(b"conv_wgrad_taps", on))
+            m = build(cfg, sd, train=True)
+            torch.nn.functional.l1_loss(m(x), t).backward()
+            torch.cuda.synchronize()
+            res[on] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+    finally:
+        check(lib().srk_set_option(b"conv_wgrad_taps", 2))
     convs = [n for n in res[0] if (".conv." in n or n.startswith(("conv_", "upsample."))) and n != "conv_first.weight"]
     assert len(convs) >= (8 if upsampler == "pixelshuffle" else 5)
     for n in convs:
@@ -177,14 +223,16 @@ def test_fused_qkv_attention_matches_separate_kernels(bs):
     x = torch.rand(bs, 3, 64, 64, generator=gen).cuda()          # shifted and unshifted blocks, masked border windows
     t = torch.rand(bs, 3, 128, 128, generator=gen).cuda()
     res = {}
-    for on in (1, 0):
-        check(lib().srk_set_option(b"attn_fused", on))
-        m = build(cfg, sd, train=True)
-        out = m(x)
-        torch.nn.functional.l1_loss(out, t).backward()
-        torch.cuda.synchronize()
-        res[on] = (out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
-    check(lib().srk_set_option(b"attn_fused", 1))
+    try:
+        for on in (1, 0):
+            check(lib().srk_set_option(b"attn_fused", on))
+            m = build(cfg, sd, train=True)
+            out = m(x)
+            torch.nn.functional.l1_loss(out, t).backward()
+            torch.cuda.synchronize()
+            res[on] = (out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
+    finally:
+        check(lib().srk_set_option(b"attn_fused", 1))
     assert torch.isfinite(res[1][0]).all()
     assert torch.equal(res[1][0], res[0][0])
     for n in res[0][1]:

@@ -30,6 +30,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SRK_SHARE_GPU") == "1":
+        local = 0            # rehearsal on a one-GPU box: every rank drives cuda:0 (gloo only; RCCL refuses duplicate GPUs)
+    backend = os.environ.get("SRK_DIST_BACKEND") or backend
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
