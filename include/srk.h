@@ -165,7 +165,11 @@ int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float
                         float weight_decay, int step, const int32_t* nonfinite, srk_stream_t stream);
 
 /* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
-enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1, SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2 };
+enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1,          /* classical SR           (network_swinir.py:740-745, :813-817) */
+       SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2,    /* lightweight SR         (:746-749, :818-822) */
+       SRK_UPSAMPLER_NEAREST_CONV = 3,          /* real-world SR, x2 / x4 (:750-759, :823-831) */
+       SRK_UPSAMPLER_NONE = 4 };                /* denoising / JPEG artefact reduction, upscale 1 (:760-762, :832-836) */
+enum { SRK_RESI_1CONV = 0, SRK_RESI_3CONV = 1 };   /* RSTB / conv_after_body residual connection (:464-471, :728-736) */
 
 typedef struct {
   int img_size;          /* constructor img_size // patch_size: only its relation to window_size matters (:193-196) */
@@ -181,6 +185,7 @@ typedef struct {
   float img_range;
   float mean[3];         /* (0.4488, 0.4371, 0.4040) for 3-channel input, 0 otherwise (:658-662) */
   float qk_scale;        /* <= 0: head_dim ** -0.5 */
+  int resi_connection;   /* SRK_RESI_* */
 } srk_swinir_config;
 
 typedef struct srk_swinir_plan srk_swinir_plan;
@@ -225,6 +230,13 @@ int srk_swinir_segment_range(const srk_swinir_plan* plan, int segment, int64_t* 
 int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* packed, float* grads, const float* d_y,
                         void* workspace, int B, int H0, int W0, const float* drop_scale, int seg_begin, int seg_end,
                         srk_stream_t stream);
+
+/* SwinIR.forward_features (network_swinir.py:790-803) as an inference entry of its own: f fp32 NCHW [B][embed_dim][H][W]
+ * (what conv_first produced) -> patch_embed norm -> RSTBs -> final norm -> out fp32 NCHW [B][embed_dim][H][W].  H and W
+ * must be multiples of window_size (the reference's window_partition needs the same).  workspace: as for a forward with
+ * training == 0 at (B, H, W).  No gradient path (inference only). */
+int srk_swinir_forward_features(srk_swinir_plan* plan, const float* params, const void* packed, const float* f, float* out,
+                                void* workspace, int B, int H, int W, srk_stream_t stream);
 
 /* Debug/parity access: byte offset and byte size of a named activation inside `workspace` for the
  * geometry of the last srk_swinir_workspace_bytes() query; returns SRK_E_STATE if unknown. */

@@ -70,8 +70,20 @@ def test_unsupported_configs_are_refused_by_the_c_api(lib):
         SwinIRPlan(**{**base, "num_heads": [3] * 6})
     with pytest.raises(ValueError, match="scale 5 is not supported"):
         SwinIRPlan(**{**base, "upscale": 5})
-    with pytest.raises(NotImplementedError):
-        SwinIRPlan(**{**base, "upsampler": "nearest+conv"})
+    with pytest.raises(NotImplementedError, match="upsamples by 2 or 4"):
+        SwinIRPlan(**{**base, "upsampler": "nearest+conv", "upscale": 3})
+    with pytest.raises(NotImplementedError, match="upscale must be 1"):
+        SwinIRPlan(**{**base, "upsampler": "", "upscale": 2})
+    with pytest.raises(ValueError, match="resi_connection"):
+        SwinIRPlan(**{**base, "resi_connection": "2conv"})
+    # every head / residual connection of the reference constructor has a plan, with the reference's parameter names
+    for ups, s in (("nearest+conv", 4), ("nearest+conv", 2), ("", 1), ("pixelshuffledirect", 2)):
+        for resi in ("1conv", "3conv"):
+            names = [q.name for q in SwinIRPlan(**{**base, "upsampler": ups, "upscale": s, "resi_connection": resi,
+                                                   "depths": [2, 2], "num_heads": [6, 6]}).params]
+            assert ("conv_up2.weight" in names) == (ups == "nearest+conv" and s == 4)
+            assert ("conv_hr.bias" in names) == (ups == "nearest+conv")
+            assert ("layers.0.conv.2.weight" in names) == (resi == "3conv") == ("conv_after_body.4.bias" in names)
 
 
 def test_index_entry_points_validate_arguments_without_a_gpu(lib):

@@ -32,7 +32,7 @@ def mutual_psnr(a, b):
     return 10 * np.log10(1.0 / max(float(((a.float() - b.float()) ** 2).mean()), 1e-20))
 
 
-@pytest.mark.parametrize("tag", ["ps4", "psd2", "ps3"])
+@pytest.mark.parametrize("tag", ["ps4", "psd2", "ps3", "nc4", "dn1", "ps2_3conv_gray"])
 def test_tiny_forward_vs_reference_golden(tag):
     g, cfg, sd = tiny_weights(tag)
     m = build(cfg, sd)
@@ -192,7 +192,7 @@ def test_errors_are_loud():
         m(torch.rand(1, 3, 16, 16))
     with pytest.raises(ValueError, match="scale 5 is not supported"):
         T.SwinIR(**{**cfg.kwargs(), "upscale": 5})
-    for bad in (dict(upsampler="nearest+conv"), dict(resi_connection="3conv"), dict(window_size=7, img_size=14), dict(ape=True)):
+    for bad in (dict(window_size=7, img_size=14), dict(ape=True), dict(patch_norm=False)):
         mm = T.SwinIR(**{**cfg.kwargs(), **bad}).cuda()
         with pytest.raises(NotImplementedError):
             mm(torch.rand(1, 3, 16, 16, device="cuda"))
@@ -266,3 +266,68 @@ def test_nan_batch_leaves_weights_intact():
     assert all(torch.equal(before[k], after[k]) for k in before)
     assert torch.equal(mom[0], opt._m) and torch.equal(mom[1], opt._v)
     assert all(bool(torch.isfinite(v).all()) for v in after.values() if v.dtype.is_floating_point)
+
+
+@pytest.mark.parametrize("tag", ["nc4", "dn1", "ps2_3conv_gray"])
+def test_other_heads_and_3conv_gradients_vs_oracle(tag):
+    """'nearest+conv' (x4: two nearest-2x stages + conv_hr), the denoising head and the '3conv' residual connection
+    (network_swinir.py:466-471, :750-762): loss and every parameter gradient against the fp32 oracle, which
+    tests/test_oracle_golden.py pins against the reference's own outputs for these three variants (G8)."""
+    g, cfg, sd = tiny_weights(tag)
+    x = torch.from_numpy(g["x_16x16"])
+    t = torch.rand(x.shape[0], cfg.in_chans, 16 * cfg.upscale, 16 * cfg.upscale, generator=torch.Generator().manual_seed(5))
+    loss_r, _, grads = O.loss_and_grads(sd, cfg, x, t)
+    m = build(cfg, sd, train=True)
+    assert [n for n, _ in m.named_parameters()] == list(grads)
+    loss = torch.nn.functional.l1_loss(m(x.cuda()), t.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_r)) <= 2e-3 * float(loss_r)
+    rels = {n: float((p.grad.cpu() - grads[n]).norm() / (grads[n].norm() + 1e-12)) for n, p in m.named_parameters()}
+    worst = max(rels, key=rels.get)
+    print(f"{tag}: grad rel-L2 median {np.median(list(rels.values())):.3e}, worst {rels[worst]:.3e} ({worst})")
+    assert rels[worst] <= 0.1, f"{worst}: {rels[worst]:.3e}"
+    assert float(np.median(list(rels.values()))) <= 0.04
+    # non-multiple-of-window training input (reflect pad + crop in both directions)
+    x2 = torch.from_numpy(g["x_13x19"])
+    t2 = torch.rand(x2.shape[0], cfg.in_chans, 13 * cfg.upscale, 19 * cfg.upscale, generator=torch.Generator().manual_seed(6))
+    _, _, grads2 = O.loss_and_grads(sd, cfg, x2, t2)
+    for p in m.parameters():
+        p.grad = None
+    torch.nn.functional.l1_loss(m(x2.cuda()), t2.cuda()).backward()
+    rels2 = [float((p.grad.cpu() - grads2[n]).norm() / (grads2[n].norm() + 1e-12)) for n, p in m.named_parameters()]
+    assert max(rels2) <= 0.12 and float(np.median(rels2)) <= 0.04
+
+
+@pytest.mark.parametrize("tag", ["ps4", "ps2_3conv_gray"])
+def test_forward_features_is_callable_and_matches_the_oracle(tag):
+    """SwinIR.forward_features (network_swinir.py:790-803) as a method of its own: conv_first output in, normed body output
+    out (fp32 NCHW), against the oracle's restatement of the same function."""
+    g, cfg, sd = tiny_weights(tag)
+    m = build(cfg, sd)
+    f = torch.randn(2, cfg.embed_dim, 16, 24, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = O.forward_features(f, sd, cfg)
+        y = m.forward_features(f.cuda()).cpu()
+    assert y.shape == ref.shape == f.shape and y.dtype == torch.float32
+    assert float((y - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+    with pytest.raises(RuntimeError, match="multiples of the window size"):
+        m.forward_features(torch.randn(1, cfg.embed_dim, 12, 16, device="cuda"))
+    m.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m.forward_features(f.cuda())
+
+
+def test_default_init_cfg3_meets_the_survey_tolerance():
+    """SURVEY 8c asks bf16-vs-fp32 max abs <= 5e-3 and mutual PSNR >= 60 dB on [0,1] images.  With weights at the reference's
+    init scale (N(0, 0.02) linears; random_state_dict(scale=1.0)) the cfg3 output stays in the image range and the HIP
+    path meets it (measured round 2: 1.6e-3 / 71 dB).  The other model tests use inflated weights (scale 1.5 - 3: outputs
+    of range 2 - 60), hence their tolerance relative to max|ref|."""
+    cfg = O.SwinIRConfig.classical_x4()
+    sd = O.random_state_dict(cfg, seed=42, scale=1.0)
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        y = build(cfg, sd)(x.cuda()).cpu()
+        ref = O.swinir_forward(sd, cfg, x)
+    assert float(ref.abs().max()) <= 1.0
+    assert float((y - ref).abs().max()) <= 5e-3
+    assert mutual_psnr(y, ref) >= 60.0

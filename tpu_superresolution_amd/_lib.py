@@ -32,11 +32,16 @@ class SwinIRConfig(C.Structure):
     _fields_ = [("img_size", C.c_int), ("in_chans", C.c_int), ("embed_dim", C.c_int), ("num_layers", C.c_int),
                 ("depths", C.c_int * 16), ("num_heads", C.c_int * 16), ("window_size", C.c_int),
                 ("hidden_dim", C.c_int), ("upscale", C.c_int), ("upsampler", C.c_int), ("img_range", C.c_float),
-                ("mean", C.c_float * 3), ("qk_scale", C.c_float)]
+                ("mean", C.c_float * 3), ("qk_scale", C.c_float), ("resi_connection", C.c_int)]
 
 
 UPSAMPLER_PIXELSHUFFLE = 1
 UPSAMPLER_PIXELSHUFFLEDIRECT = 2
+UPSAMPLER_NEAREST_CONV = 3
+UPSAMPLER_NONE = 4
+UPSAMPLERS = {"pixelshuffle": UPSAMPLER_PIXELSHUFFLE, "pixelshuffledirect": UPSAMPLER_PIXELSHUFFLEDIRECT,
+              "nearest+conv": UPSAMPLER_NEAREST_CONV, "": UPSAMPLER_NONE}
+RESI = {"1conv": 0, "3conv": 1}
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _geom_p = C.POINTER(WinGeom)
@@ -84,6 +89,7 @@ _SIGNATURES = {
     "srk_swinir_pack": (_i, [_vp, _vp, _vp, _vp]),
     "srk_swinir_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "srk_swinir_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "srk_swinir_forward_features": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srk_swinir_num_segments": (_i, [_vp]),
     "srk_swinir_segment_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "srk_swinir_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),

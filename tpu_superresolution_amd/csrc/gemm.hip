@@ -327,8 +327,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             const int rr = p.r * p.r;
             const int c = nn / rr, ij = nn - c * rr;
             const int oy = y * p.r + ij / p.r, ox = x * p.r + ij % p.r;
+            // denoising head (network_swinir.py:836-838): x + conv_last(res), x = the normalised input image [M][4] (r == 1)
+            const float add = (p.res != nullptr && c < 4) ? p.res[(long long)m * 4 + c] : 0.f;
             if (c < p.Cimg && oy < p.Hc && ox < p.Wc)
-              p.outf[(((long long)b * p.Cimg + c) * p.Hc + oy) * p.Wc + ox] = vv[e] * p.inv_range + p.mean[c];
+              p.outf[(((long long)b * p.Cimg + c) * p.Hc + oy) * p.Wc + ox] = (vv[e] + add) * p.inv_range + p.mean[c];
           }
         }
       }
@@ -403,6 +405,8 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
   CASE(LD_ROWS, EP_RES)
   CASE(LD_ROWS, EP_DGELU)
   CASE(LD_ROWS, EP_LNBWD)
+  CASE(LD_ROWS, EP_LRELU)       // 1x1 conv of the '3conv' residual connection (network_swinir.py:466-471)
+  CASE(LD_ROWS, EP_DLRELU)
   CASE(LD_CONV3, EP_RES)
   CASE(LD_CONV3, EP_RES_BF16)
   CASE(LD_CONV3, EP_LRELU)

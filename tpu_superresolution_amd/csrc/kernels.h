@@ -44,6 +44,10 @@ int srk_launch_batch_psnr(const float* pred, const float* target, float* partial
 int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream);
 int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStream_t stream);
 int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream);
+int srk_launch_dlrelu_bf16(bf16_t* g, const bf16_t* act, float slope, long long n, hipStream_t stream);
+int srk_launch_nn2x_bf16(const bf16_t* in, bf16_t* out, int B, int h, int w, int C, hipStream_t stream);
+int srk_launch_nn2x_sum_dlrelu(const bf16_t* g, const bf16_t* act, bf16_t* out, int B, int h, int w, int C, float slope, hipStream_t stream);
+int srk_launch_nchw_tokens(const float* src, float* dst, int B, int C, int CP, int HW, int to_tokens, hipStream_t stream);
 int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, float* loss_sum, unsigned* nonfinite, long long n, float grad_scale, hipStream_t stream);
 int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream);
 int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, const int* nonfinite, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t stream);

@@ -516,6 +516,93 @@ __global__ void dlrelu_bf16_kernel(bf16_t* __restrict__ g, const bf16_t* __restr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 'nearest+conv' head (network_swinir.py:828-835): F.interpolate(scale_factor=2, mode='nearest') on NHWC bf16 and its
+// backward (sum of the 2x2 children), the latter fused with the LeakyReLU derivative of the tensor that was upsampled
+// (it is a conv + LeakyReLU output): gp = (g00 + g01 + g10 + g11) * (act > 0 ? 1 : slope), sums in fp32.
+// One thread = 8 channels (16 bytes); C % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void nn2x_bf16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int B, int h, int w, int c8) {
+  const long long total = (long long)B * 2 * h * 2 * w * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    long long px = i / c8;
+    const int x = (int)(px % (2 * w));
+    px /= 2 * w;
+    const int y = (int)(px % (2 * h));
+    const long long b = px / (2 * h);
+    out[i] = in[((b * h + (y >> 1)) * w + (x >> 1)) * c8 + cc];
+  }
+}
+
+__global__ void nn2x_sum_dlrelu_kernel(const uint4* __restrict__ g, const uint4* __restrict__ act, uint4* __restrict__ out, int B,
+                                       int h, int w, int c8, float slope) {
+  const long long total = (long long)B * h * w * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    long long px = i / c8;
+    const int x = (int)(px % w);
+    px /= w;
+    const int y = (int)(px % h);
+    const long long b = px / h;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint4 v = g[((b * 2 * h + 2 * y + (d >> 1)) * (2 * w) + 2 * x + (d & 1)) * c8 + cc];
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo, hi;
+        unpack_bf2(u[e], lo, hi);
+        s[2 * e] += lo;
+        s[2 * e + 1] += hi;
+      }
+    }
+    const uint4 a = act[i];
+    const unsigned au[4] = {a.x, a.y, a.z, a.w};
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo, hi;
+      unpack_bf2(au[e], lo, hi);
+      o[e] = pack_bf2(lo > 0.f ? s[2 * e] : s[2 * e] * slope, hi > 0.f ? s[2 * e + 1] : s[2 * e + 1] * slope);
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// forward_features as a stand-alone entry (network_swinir.py:790-803): NCHW fp32 [B][C][H][W] <-> token-major fp32 [B*H*W][CP]
+// (pad columns zero).  32 x 32 (pixel, channel) tiles through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void nchw_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int CP,
+                                                          int HW, int to_tokens) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (to_tokens) {
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r, px = p0 + tx;
+      tile[r][tx] = (c < C && px < HW) ? src[(b * C + c) * HW + px] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int px = p0 + r, c = c0 + tx;
+      if (px < HW && c < CP) dst[(b * HW + px) * CP + c] = tile[tx][r];
+    }
+  } else {
+    for (int r = ty; r < 32; r += 8) {
+      const int px = p0 + r, c = c0 + tx;
+      tile[r][tx] = (px < HW && c < C) ? src[(b * HW + px) * CP + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r, px = p0 + tx;
+      if (c < C && px < HW) dst[(b * C + c) * HW + px] = tile[tx][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // L1 loss (finetune_swinir.py:66-67) forward + backward, with a non-finite counter (:133-143)
 // ------------------------------------------------------------------------------------------------
@@ -854,6 +941,30 @@ int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream
 int srk_launch_dlrelu_bf16(bf16_t* g, const bf16_t* act, float slope, long long n, hipStream_t stream) {
   hipLaunchKernelGGL(dlrelu_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, g, act, slope, n);
   return srk_check_launch("dlrelu");
+}
+
+
+int srk_launch_nn2x_bf16(const bf16_t* in, bf16_t* out, int B, int h, int w, int C, hipStream_t stream) {
+  SRK_REQUIRE(C % 8 == 0, SRK_E_SHAPE, "nearest 2x: C=%d must be a multiple of 8", C);
+  hipLaunchKernelGGL(nn2x_bf16_kernel, dim3(grid_for((long long)B * 4 * h * w * (C / 8))), dim3(256), 0, stream,
+                     reinterpret_cast<const uint4*>(in), reinterpret_cast<uint4*>(out), B, h, w, C / 8);
+  return srk_check_launch("nn2x");
+}
+
+int srk_launch_nn2x_sum_dlrelu(const bf16_t* g, const bf16_t* act, bf16_t* out, int B, int h, int w, int C, float slope,
+                               hipStream_t stream) {
+  SRK_REQUIRE(C % 8 == 0, SRK_E_SHAPE, "nearest 2x backward: C=%d must be a multiple of 8", C);
+  hipLaunchKernelGGL(nn2x_sum_dlrelu_kernel, dim3(grid_for((long long)B * h * w * (C / 8))), dim3(256), 0, stream,
+                     reinterpret_cast<const uint4*>(g), reinterpret_cast<const uint4*>(act), reinterpret_cast<uint4*>(out), B, h, w,
+                     C / 8, slope);
+  return srk_check_launch("nn2x_sum_dlrelu");
+}
+
+int srk_launch_nchw_tokens(const float* src, float* dst, int B, int C, int CP, int HW, int to_tokens, hipStream_t stream) {
+  SRK_REQUIRE(B > 0 && B < 65536 && CP >= C, SRK_E_SHAPE, "nchw<->tokens: bad shape B=%d C=%d CP=%d", B, C, CP);
+  dim3 grid((HW + 31) / 32, (CP + 31) / 32, B);
+  hipLaunchKernelGGL(nchw_tokens_kernel, grid, dim3(256), 0, stream, src, dst, C, CP, HW, to_tokens);
+  return srk_check_launch("nchw_tokens");
 }
 
 int srk_launch_l1_loss(const float* pred, const float* target, float* dpred, float* loss_sum, unsigned* nonfinite,

@@ -35,6 +35,20 @@ struct ConvW {
   int Cin, CinP, Cout, NP, r, Cs;
 };
 
+// residual-connection conv of an RSTB / conv_after_body: '1conv' = one 3x3 conv; '3conv' = conv3x3(C -> C/4) + LeakyReLU(0.2)
+// + conv1x1(C/4 -> C/4) + LeakyReLU(0.2) + conv3x3(C/4 -> C)   (network_swinir.py:464-471, :728-736)
+struct ResiW {
+  int three = 0;
+  ConvW c;               // '1conv'
+  ConvW c0, c2;          // '3conv' outer convs (C/4 padded to 64 channels)
+  long long w1 = 0, b1 = 0, W1 = 0, W1T = 0, b1s = 0;   // the 1x1 conv as a 64 x 64 linear layer: flat params, packed, side bias
+  int C4 = 0;
+};
+
+struct ResiAct {
+  size_t a1 = 0, a2 = 0;   // bf16 [T][64]: LeakyReLU outputs after conv0 / conv1x1 (saved for backward when training)
+};
+
 struct BlockAct {
   size_t x_in, xn1w, mean1, rstd1, qkv, ao, x1, xn2, mean2, rstd2, u, h, x_out;
 };
@@ -47,8 +61,13 @@ struct Workspace {
   std::vector<size_t> layer_in, layer_xb, layer_out;
   size_t meanf, rstdf, xnf, fb, t1;
   std::vector<size_t> up;      // pixel-shuffled activations per stage
+  std::vector<ResiAct> resi;   // '3conv': per RSTB, last entry = conv_after_body
+  std::vector<size_t> nc_u, nc_a;   // 'nearest+conv': nearest-upsampled inputs / LeakyReLU outputs of conv_up1, conv_up2
+  size_t nc_hr = 0;                 // LeakyReLU(conv_hr)
   // backward
   size_t gx, gxb, gx2, gxb2, gxbw, du, dxn, dao, dqkv, slab, wgpart, gyimg, gt1, gfb, gfb32, gstage_w, gstage_side;
+  size_t g3a = 0, g3b = 0;          // '3conv': bf16 [T][64] gradients of the two narrow activations
+  size_t ncgA = 0, ncgB = 0, ncgU = 0;   // 'nearest+conv': bf16 gradient buffers at the output resolution
   std::vector<size_t> gup;
   size_t total = 0;
   std::map<std::string, std::pair<size_t, size_t>> names;
@@ -65,9 +84,10 @@ struct srk_swinir_plan {
   long long param_floats = 0;
   std::vector<BlockW> blocks;
   std::vector<int> layer_first_blk;
-  std::vector<ConvW> layer_conv;
-  ConvW conv_after_body, conv_before_up, conv_last, up_direct;
-  std::vector<ConvW> up_convs;
+  std::vector<ResiW> layer_conv;
+  ResiW conv_after_body;
+  ConvW conv_before_up, conv_last, up_direct, conv_hr;
+  std::vector<ConvW> up_convs;       // 'pixelshuffle': conv + PixelShuffle stages; 'nearest+conv': conv_up1, conv_up2
   long long p_conv_first_w, p_conv_first_b, p_pe_w, p_pe_b, p_norm_w, p_norm_b;
   // pack descriptors, grouped: group 0 = head, 1..L = layers, L+1 = tail
   std::vector<PackDesc> descs;
@@ -160,6 +180,25 @@ void add_conv(srk_swinir_plan* p, ConvW& c, const std::string& name, int Cout, i
   add_vec(p, c.b, c.bc, NP, Cout, r > 1 ? NM_PS : NM_DIRECT, 1, 1, r, Cs);
 }
 
+void add_resi(srk_swinir_plan* p, ResiW& r, const std::string& name, int C, int CP) {
+  r.three = p->cfg.resi_connection == SRK_RESI_3CONV;
+  if (!r.three) {
+    add_conv(p, r.c, name, C, C, CP, CP, 1, 64, true);
+    return;
+  }
+  const int C4 = C / 4;
+  r.C4 = C4;
+  add_conv(p, r.c0, name + ".0", C4, C, 64, CP, 1, 64, true);
+  r.w1 = add_param(p, name + ".2.weight", {C4, C4, 1, 1});
+  r.b1 = add_param(p, name + ".2.bias", {C4});
+  r.W1 = alloc_packed(p, 64 * 64);
+  r.W1T = alloc_packed(p, 64 * 64);
+  r.b1s = alloc_side(p, 64);
+  add_linear(p, r.w1, r.W1, r.W1T, 64, 64, C4, C4, NM_DIRECT, KM_DIRECT, 1, 1);
+  add_vec(p, r.b1, r.b1s, 64, C4, NM_DIRECT, 1, 1, 1, 64);
+  add_conv(p, r.c2, name + ".4", C, C4, CP, 64, 1, 64, true);
+}
+
 void finish_group(srk_swinir_plan* p) {
   const int begin = p->group_desc_begin.back();
   int blocks = 0;
@@ -227,6 +266,7 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
     pingQ = a.get("pingQ", T * CP * 4);
     shared_xb = a.get("xb", T * CP * 2);
   }
+  w.resi.assign(p->L + 1, ResiAct());
   size_t cur = w.x0;
   for (int l = 0; l < p->L; ++l) {
     w.layer_in[l] = cur;
@@ -259,6 +299,11 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
       }
       cur = ba.x_out;
     }
+    if (p->cfg.resi_connection == SRK_RESI_3CONV) {
+      const std::string pre = training ? "layer" + std::to_string(l) + "." : "shared.";
+      w.resi[l].a1 = (training || l == 0) ? a.get(pre + "resi_a1", T * 64 * 2) : w.resi[0].a1;
+      w.resi[l].a2 = (training || l == 0) ? a.get(pre + "resi_a2", T * 64 * 2) : w.resi[0].a2;
+    }
     w.layer_xb[l] = training ? a.get("layer" + std::to_string(l) + ".xb", T * CP * 2) : shared_xb;
     // RSTB output: new buffer when training (the block input must survive), in place otherwise
     w.layer_out[l] = training ? a.get("layer" + std::to_string(l) + ".out", T * CP * 4) : w.layer_in[l];
@@ -268,7 +313,12 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
   w.rstdf = a.get("rstdf", T * 4);
   w.xnf = a.get("xnf", T * CP * 2);
   w.fb = a.get("fb", T * CP * 2);
+  if (p->cfg.resi_connection == SRK_RESI_3CONV) {
+    w.resi[p->L].a1 = (training || p->L == 0) ? a.get("tail.resi_a1", T * 64 * 2) : w.resi[0].a1;
+    w.resi[p->L].a2 = (training || p->L == 0) ? a.get("tail.resi_a2", T * 64 * 2) : w.resi[0].a2;
+  }
   w.t1 = 0;
+  size_t out_px = T;          // pixels at the output resolution
   if (p->cfg.upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
     w.t1 = a.get("t1", T * 64 * 2);
     size_t px = T;
@@ -276,6 +326,17 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
       px *= (size_t)p->stage_r * p->stage_r;
       w.up.push_back(a.get("up" + std::to_string(k), px * 64 * 2));
     }
+    out_px = px;
+  } else if (p->cfg.upsampler == SRK_UPSAMPLER_NEAREST_CONV) {
+    w.t1 = a.get("t1", T * 64 * 2);
+    size_t px = T;
+    for (int k = 0; k < p->nstage; ++k) {
+      px *= 4;
+      w.nc_u.push_back(a.get("nc_u" + std::to_string(k), px * 64 * 2));
+      w.nc_a.push_back(a.get("nc_a" + std::to_string(k), px * 64 * 2));
+    }
+    w.nc_hr = a.get("nc_hr", px * 64 * 2);
+    out_px = px;
   }
   if (training) {
     w.gx = a.get("gx", T * CP * 4);
@@ -293,7 +354,17 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
     w.wgpart = a.get("wgpart", WS_WORKSPACE_BYTES);      // split partials of the streaming weight-gradient kernels
     w.gfb = a.get("gfb", T * CP * 2);
     w.gfb32 = a.get("gfb32", T * CP * 4);
-    if (p->cfg.upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
+    if (p->cfg.resi_connection == SRK_RESI_3CONV) {
+      w.g3a = a.get("g3a", T * 64 * 2);
+      w.g3b = a.get("g3b", T * 64 * 2);
+    }
+    if (p->cfg.upsampler == SRK_UPSAMPLER_NEAREST_CONV) {
+      w.gt1 = a.get("gt1", T * 64 * 2);
+      w.ncgA = a.get("ncgA", out_px * 64 * 2);
+      w.ncgB = a.get("ncgB", out_px * 64 * 2);
+      w.ncgU = a.get("ncgU", out_px * 64 * 2);
+      w.gyimg = a.get("gyimg", out_px * 4 * 4);
+    } else if (p->cfg.upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
       w.gt1 = a.get("gt1", T * 64 * 2);
       size_t px = T;
       for (int k = 0; k < p->nstage; ++k) {
@@ -363,8 +434,12 @@ int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** out) 
   SRK_REQUIRE(cfg->embed_dim > 0 && cfg->embed_dim <= 256, SRK_E_UNSUPPORTED, "embed_dim must be <= 256 (got %d)", cfg->embed_dim);
   SRK_REQUIRE(cfg->num_layers > 0 && cfg->num_layers <= 16, SRK_E_UNSUPPORTED, "num_layers must be 1..16");
   SRK_REQUIRE(cfg->hidden_dim > 0 && cfg->hidden_dim <= 1024, SRK_E_UNSUPPORTED, "hidden_dim must be <= 1024");
-  SRK_REQUIRE(cfg->upsampler == SRK_UPSAMPLER_PIXELSHUFFLE || cfg->upsampler == SRK_UPSAMPLER_PIXELSHUFFLEDIRECT,
-              SRK_E_UNSUPPORTED, "HIP path supports upsampler 'pixelshuffle' and 'pixelshuffledirect' only");
+  SRK_REQUIRE(cfg->upsampler >= SRK_UPSAMPLER_PIXELSHUFFLE && cfg->upsampler <= SRK_UPSAMPLER_NONE, SRK_E_UNSUPPORTED,
+              "unknown upsampler code %d", cfg->upsampler);
+  SRK_REQUIRE(cfg->resi_connection == SRK_RESI_1CONV || cfg->resi_connection == SRK_RESI_3CONV, SRK_E_UNSUPPORTED,
+              "unknown resi_connection code %d", cfg->resi_connection);
+  SRK_REQUIRE(cfg->resi_connection == SRK_RESI_1CONV || (cfg->embed_dim / 4 >= 1 && cfg->embed_dim / 4 <= 64), SRK_E_UNSUPPORTED,
+              "'3conv' needs embed_dim / 4 <= 64 (got %d)", cfg->embed_dim / 4);
   const int s = cfg->upscale;
   int nstage = 0, stage_r = 1;
   if (cfg->upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
@@ -378,9 +453,16 @@ int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** out) 
       srk_set_error("scale %d is not supported. Supported scales: 2^n and 3.", s);   // network_swinir.py:590
       return SRK_E_SHAPE;
     }
-  } else {
+  } else if (cfg->upsampler == SRK_UPSAMPLER_PIXELSHUFFLEDIRECT) {
     SRK_REQUIRE(s >= 1 && s * s * cfg->in_chans <= 16, SRK_E_UNSUPPORTED,
                 "HIP 'pixelshuffledirect' path supports upscale^2 * in_chans <= 16 (got %d)", s * s * cfg->in_chans);
+  } else if (cfg->upsampler == SRK_UPSAMPLER_NEAREST_CONV) {
+    // the reference applies conv_up1 always and conv_up2 only for upscale == 4 (network_swinir.py:831-834): x2 or x4
+    SRK_REQUIRE(s == 2 || s == 4, SRK_E_UNSUPPORTED, "'nearest+conv' upsamples by 2 or 4 (got %d)", s);
+    stage_r = 2;
+    nstage = s == 4 ? 2 : 1;
+  } else {
+    SRK_REQUIRE(s == 1, SRK_E_UNSUPPORTED, "the denoising head (upsampler '') keeps the image size: upscale must be 1 (got %d)", s);
   }
   srk_swinir_plan* p = new srk_swinir_plan();
   p->cfg = *cfg;
@@ -453,16 +535,27 @@ int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** out) 
       p->blocks.push_back(b);
       ++p->nblk;
     }
-    ConvW cw;
-    add_conv(p, cw, "layers." + std::to_string(l) + ".conv", C, C, CP, CP, 1, 64, true);
-    p->layer_conv.push_back(cw);
+    ResiW rw;
+    add_resi(p, rw, "layers." + std::to_string(l) + ".conv", C, CP);
+    p->layer_conv.push_back(rw);
     finish_group(p);
   }
   // ---- group L+1: tail ----
   p->p_norm_w = add_param(p, "norm.weight", {C});
   p->p_norm_b = add_param(p, "norm.bias", {C});
-  add_conv(p, p->conv_after_body, "conv_after_body", C, C, CP, CP, 1, 64, true);
-  if (cfg->upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
+  add_resi(p, p->conv_after_body, "conv_after_body", C, CP);
+  if (cfg->upsampler == SRK_UPSAMPLER_NEAREST_CONV) {            // network_swinir.py:750-759 (registration order)
+    add_conv(p, p->conv_before_up, "conv_before_upsample.0", 64, C, 64, CP, 1, 64, true);
+    for (int k = 0; k < nstage; ++k) {
+      ConvW cw;
+      add_conv(p, cw, "conv_up" + std::to_string(k + 1), 64, 64, 64, 64, 1, 64, true);
+      p->up_convs.push_back(cw);
+    }
+    add_conv(p, p->conv_hr, "conv_hr", 64, 64, 64, 64, 1, 64, true);
+    add_conv(p, p->conv_last, "conv_last", cfg->in_chans, 64, 16, 64, 1, 64, false);
+  } else if (cfg->upsampler == SRK_UPSAMPLER_NONE) {              // :760-762: conv_last C -> in_chans, added to the input
+    add_conv(p, p->up_direct, "conv_last", cfg->in_chans, C, 16, CP, 1, 64, false);
+  } else if (cfg->upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
     add_conv(p, p->conv_before_up, "conv_before_upsample.0", 64, C, 64, CP, 1, 64, true);
     for (int k = 0; k < nstage; ++k) {
       ConvW cw;
@@ -555,19 +648,49 @@ int srk_swinir_segment_range(const srk_swinir_plan* plan, int segment, int64_t* 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* packed, const float* x, float* y,
-                       void* workspace, int B, int H0, int W0, int training, const float* drop_scale, srk_stream_t stream_) {
-  SRK_REQUIRE(plan && params && packed && x && y && workspace, SRK_E_NULL, "forward: null argument");
-  SRK_REQUIRE(B > 0 && H0 > 0 && W0 > 0, SRK_E_SHAPE, "forward: bad shape B=%d H=%d W=%d", B, H0, W0);
-  srk_swinir_plan* p = plan;
-  Workspace& w = p->ws;
-  if (w.B != B || w.H0 != H0 || w.W0 != W0 || w.training != training) layout_workspace(p, w, B, H0, W0, training);
-  SRK_REQUIRE((H0 % 8 == 0 || H0 >= 2) && (W0 % 8 == 0 || W0 >= 2), SRK_E_SHAPE, "forward: reflect padding needs size >= 2");
-  SRK_REQUIRE(w.H - H0 < H0 && w.W - W0 < W0, SRK_E_SHAPE,
-              "forward: reflect padding %dx%d -> %dx%d needs pad < size (as torch 'reflect')", H0, W0, w.H, w.W);
-  SRK_REQUIRE(w.T < (1LL << 31) / 4, SRK_E_SHAPE, "forward: too many tokens (%lld)", w.T);
-  Ctx c = {p, params, reinterpret_cast<const bf16_t*>(packed), side_of(p, packed), reinterpret_cast<unsigned char*>(workspace),
-           (hipStream_t)stream_};
+}  // extern "C"
+
+namespace {
+
+// epilogue-side description of what follows a residual-connection conv: the LayerNorm that consumes its output
+struct NextNorm {
+  bf16_t* out = nullptr;
+  float *mean = nullptr, *rstd = nullptr;
+  const float *gamma = nullptr, *beta = nullptr;
+  int window = 0;
+  WinGeom geom = {};
+};
+
+void set_xn(GemmParams& g, const NextNorm& nn, int C) {
+  if (!nn.out) return;
+  g.xn_out = nn.out; g.xn_mean = nn.mean; g.xn_rstd = nn.rstd; g.xn_gamma = nn.gamma; g.xn_beta = nn.beta; g.xn_C = C;
+  g.xn_window = nn.window; g.xn_geom = nn.geom;
+}
+
+// RSTB conv / conv_after_body forward: in bf16 [T][CP] -> (EP_RES: outf = res + conv, optional fused next LayerNorm) or
+// (EP_RES_BF16: outb = bf16(res + conv)).  '3conv' runs conv3x3 -> LeakyReLU(0.2) -> conv1x1 -> LeakyReLU(0.2) -> conv3x3.
+int resi_forward(const Ctx& c, const ResiW& rw, const ResiAct& ra, const bf16_t* in, int ep, GemmParams g, int B, int H, int W) {
+  if (!rw.three) return run_conv(c, rw.c, LD_CONV3, ep, in, B, H, W, g);
+  const int T = B * H * W;
+  {
+    GemmParams q = {};
+    q.outb = c.at<bf16_t>(ra.a1); q.scale = 0.2f;
+    RUN(run_conv(c, rw.c0, LD_CONV3, EP_LRELU, in, B, H, W, q));
+  }
+  {
+    GemmParams q = {};
+    q.A = c.at<bf16_t>(ra.a1); q.lda = 64; q.Wt = c.packed + rw.W1; q.M = T; q.N = 64; q.K = 64; q.bias = c.side + rw.b1s;
+    q.outb = c.at<bf16_t>(ra.a2); q.ldo = 64; q.scale = 0.2f; q.flops = 2.0 * T * rw.C4 * rw.C4;
+    RUN(srk_launch_gemm(LD_ROWS, EP_LRELU, q, c.stream));
+  }
+  return run_conv(c, rw.c2, LD_CONV3, ep, c.at<bf16_t>(ra.a2), B, H, W, g);
+}
+
+// patch_embed.norm -> RSTBs (-> final norm fused into the last RSTB conv when fuse_final).  f0 holds conv_first's output.
+int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) {
+  srk_swinir_plan* p = c.p;
+  const Workspace& w = p->ws;
+  const float* params = c.params;
   const int H = w.H, W = w.W, C = p->C, CP = p->CP, HP = p->HP;
   const int T = (int)w.T;
   const int HW = H * W;
@@ -576,9 +699,6 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
   const bool fuse_ln = CP == 64 || CP == 128 || CP == 192;   // forward LayerNorms ride in the producing GEMM's epilogue
   bool ln1_done = false;
 
-  RUN(srk_launch_img_prep(x, c.at<float>(w.img4), B, p->Cimg, H0, W0, H, W, p->cfg.img_range, p->cfg.mean, st));
-  RUN(srk_launch_stem_conv(c.at<float>(w.img4), params + p->p_conv_first_w, params + p->p_conv_first_b, c.at<float>(w.f0), B, H,
-                           W, p->Cimg, C, CP, st));
   RUN(srk_launch_ln_fwd(c.at<float>(w.f0), params + p->p_pe_w, params + p->p_pe_b, nullptr, c.at<float>(w.x0),
                         c.at<float>(w.mean_pe), c.at<float>(w.rstd_pe), T, C, CP, nullptr, st));
 
@@ -657,29 +777,56 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
     {  // RSTB conv + residual                          :481-482
       GemmParams g = {};
       g.res = c.at<float>(w.layer_in[l]); g.outf = c.at<float>(w.layer_out[l]); g.ldo = CP;
+      NextNorm nn;
       if (fuse_ln && l + 1 < p->L) {     // norm1 of the next RSTB's first block
         const int nbi = p->layer_first_blk[l + 1];
         const BlockW& nb = p->blocks[nbi];
         const BlockAct& na = w.blk[nbi];
-        g.xn_out = c.at<bf16_t>(na.xn1w); g.xn_mean = c.at<float>(na.mean1); g.xn_rstd = c.at<float>(na.rstd1);
-        g.xn_gamma = params + nb.n1w; g.xn_beta = params + nb.n1b; g.xn_C = C; g.xn_window = 1;
-        g.xn_geom = make_wgeom(H, W, nb.shift);
+        nn.out = c.at<bf16_t>(na.xn1w); nn.mean = c.at<float>(na.mean1); nn.rstd = c.at<float>(na.rstd1);
+        nn.gamma = params + nb.n1w; nn.beta = params + nb.n1b; nn.window = 1; nn.geom = make_wgeom(H, W, nb.shift);
         ln1_done = true;
-      } else if (fuse_ln) {              // final norm (:800)
-        g.xn_out = c.at<bf16_t>(w.xnf); g.xn_mean = c.at<float>(w.meanf); g.xn_rstd = c.at<float>(w.rstdf);
-        g.xn_gamma = params + p->p_norm_w; g.xn_beta = params + p->p_norm_b; g.xn_C = C; g.xn_window = 0;
+      } else if (fuse_ln && fuse_final) {              // final norm (:800)
+        nn.out = c.at<bf16_t>(w.xnf); nn.mean = c.at<float>(w.meanf); nn.rstd = c.at<float>(w.rstdf);
+        nn.gamma = params + p->p_norm_w; nn.beta = params + p->p_norm_b;
       }
-      RUN(run_conv(c, p->layer_conv[l], LD_CONV3, EP_RES, c.at<bf16_t>(w.layer_xb[l]), B, H, W, g));
+      set_xn(g, nn, C);
+      RUN(resi_forward(c, p->layer_conv[l], w.resi[l], c.at<bf16_t>(w.layer_xb[l]), EP_RES, g, B, H, W));
     }
   }
-  const size_t x_final = w.layer_out[p->L - 1];
-  if (!fuse_ln)   // final norm                          :800
-    RUN(srk_launch_ln_fwd(c.at<float>(x_final), params + p->p_norm_w, params + p->p_norm_b, c.at<bf16_t>(w.xnf), nullptr,
+  if (!fuse_ln && fuse_final)   // final norm                          :800
+    RUN(srk_launch_ln_fwd(c.at<float>(w.layer_out[p->L - 1]), params + p->p_norm_w, params + p->p_norm_b, c.at<bf16_t>(w.xnf), nullptr,
                           c.at<float>(w.meanf), c.at<float>(w.rstdf), T, C, CP, nullptr, st));
+  return SRK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* packed, const float* x, float* y,
+                       void* workspace, int B, int H0, int W0, int training, const float* drop_scale, srk_stream_t stream_) {
+  SRK_REQUIRE(plan && params && packed && x && y && workspace, SRK_E_NULL, "forward: null argument");
+  SRK_REQUIRE(B > 0 && H0 > 0 && W0 > 0, SRK_E_SHAPE, "forward: bad shape B=%d H=%d W=%d", B, H0, W0);
+  srk_swinir_plan* p = plan;
+  Workspace& w = p->ws;
+  if (w.B != B || w.H0 != H0 || w.W0 != W0 || w.training != training) layout_workspace(p, w, B, H0, W0, training);
+  SRK_REQUIRE((H0 % 8 == 0 || H0 >= 2) && (W0 % 8 == 0 || W0 >= 2), SRK_E_SHAPE, "forward: reflect padding needs size >= 2");
+  SRK_REQUIRE(w.H - H0 < H0 && w.W - W0 < W0, SRK_E_SHAPE,
+              "forward: reflect padding %dx%d -> %dx%d needs pad < size (as torch 'reflect')", H0, W0, w.H, w.W);
+  SRK_REQUIRE(w.T < (1LL << 31) / 4, SRK_E_SHAPE, "forward: too many tokens (%lld)", w.T);
+  Ctx c = {p, params, reinterpret_cast<const bf16_t*>(packed), side_of(p, packed), reinterpret_cast<unsigned char*>(workspace),
+           (hipStream_t)stream_};
+  const int H = w.H, W = w.W, C = p->C, CP = p->CP;
+  hipStream_t st = c.stream;
+
+  RUN(srk_launch_img_prep(x, c.at<float>(w.img4), B, p->Cimg, H0, W0, H, W, p->cfg.img_range, p->cfg.mean, st));
+  RUN(srk_launch_stem_conv(c.at<float>(w.img4), params + p->p_conv_first_w, params + p->p_conv_first_b, c.at<float>(w.f0), B, H,
+                           W, p->Cimg, C, CP, st));
+  RUN(forward_body(c, B, drop_scale, true));
   {  // conv_after_body + long skip                      :815
     GemmParams g = {};
     g.res = c.at<float>(w.f0); g.outb = c.at<bf16_t>(w.fb); g.ldo = CP;
-    RUN(run_conv(c, p->conv_after_body, LD_CONV3, EP_RES_BF16, c.at<bf16_t>(w.xnf), B, H, W, g));
+    RUN(resi_forward(c, p->conv_after_body, w.resi[p->L], c.at<bf16_t>(w.xnf), EP_RES_BF16, g, B, H, W));
   }
   const int s = p->cfg.upscale;
   GemmParams img = {};
@@ -704,10 +851,58 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
     }
     img.r = 1;
     RUN(run_conv(c, p->conv_last, LD_CONV3, EP_IMG, cur, B, h, ww, img));   // conv_last, /range + mean, crop  :817,:838-840
+  } else if (p->cfg.upsampler == SRK_UPSAMPLER_NEAREST_CONV) {
+    {  // conv_before_upsample + LeakyReLU(0.01)           :826
+      GemmParams g = {};
+      g.outb = c.at<bf16_t>(w.t1); g.scale = 0.01f;
+      RUN(run_conv(c, p->conv_before_up, LD_CONV3, EP_LRELU, c.at<bf16_t>(w.fb), B, H, W, g));
+    }
+    const bf16_t* cur = c.at<bf16_t>(w.t1);
+    int h = H, ww = W;
+    for (int k = 0; k < p->nstage; ++k) {  // lrelu(conv_up_k(nearest x2))   :827-829, LeakyReLU(0.2) :759
+      RUN(srk_launch_nn2x_bf16(cur, c.at<bf16_t>(w.nc_u[k]), B, h, ww, 64, st));
+      h *= 2;
+      ww *= 2;
+      GemmParams g = {};
+      g.outb = c.at<bf16_t>(w.nc_a[k]); g.scale = 0.2f;
+      RUN(run_conv(c, p->up_convs[k], LD_CONV3, EP_LRELU, c.at<bf16_t>(w.nc_u[k]), B, h, ww, g));
+      cur = c.at<bf16_t>(w.nc_a[k]);
+    }
+    {  // lrelu(conv_hr)                                   :830
+      GemmParams g = {};
+      g.outb = c.at<bf16_t>(w.nc_hr); g.scale = 0.2f;
+      RUN(run_conv(c, p->conv_hr, LD_CONV3, EP_LRELU, cur, B, h, ww, g));
+    }
+    img.r = 1;
+    RUN(run_conv(c, p->conv_last, LD_CONV3, EP_IMG, c.at<bf16_t>(w.nc_hr), B, h, ww, img));
+  } else if (p->cfg.upsampler == SRK_UPSAMPLER_NONE) {
+    img.r = 1;                                 // x + conv_last(res)   :832-836 (x = the normalised, padded input)
+    img.res = c.at<float>(w.img4);
+    RUN(run_conv(c, p->up_direct, LD_CONV3, EP_PS_IMG, c.at<bf16_t>(w.fb), B, H, W, img));
   } else {
     img.r = s;
     RUN(run_conv(c, p->up_direct, LD_CONV3, EP_PS_IMG, c.at<bf16_t>(w.fb), B, H, W, img));   // UpsampleOneStep :594-615
   }
+  return SRK_OK;
+}
+
+int srk_swinir_forward_features(srk_swinir_plan* plan, const float* params, const void* packed, const float* f, float* out,
+                                void* workspace, int B, int H, int W, srk_stream_t stream_) {
+  SRK_REQUIRE(plan && params && packed && f && out && workspace, SRK_E_NULL, "forward_features: null argument");
+  SRK_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, SRK_E_SHAPE,
+              "forward_features: H and W must be positive multiples of the window size 8 (got %dx%d)", H, W);
+  srk_swinir_plan* p = plan;
+  Workspace& w = p->ws;
+  if (w.B != B || w.H0 != H || w.W0 != W || w.training != 0) layout_workspace(p, w, B, H, W, 0);
+  SRK_REQUIRE(w.T < (1LL << 31) / 4, SRK_E_SHAPE, "forward_features: too many tokens (%lld)", w.T);
+  Ctx c = {p, params, reinterpret_cast<const bf16_t*>(packed), side_of(p, packed), reinterpret_cast<unsigned char*>(workspace),
+           (hipStream_t)stream_};
+  RUN(srk_launch_nchw_tokens(f, c.at<float>(w.f0), B, p->C, p->CP, H * W, 1, c.stream));        // PatchEmbed :524-528
+  RUN(forward_body(c, B, nullptr, false));
+  // final norm in fp32 (:800), then PatchUnEmbed (:562-565); f0 is free again (the long skip lives outside this function)
+  RUN(srk_launch_ln_fwd(c.at<float>(w.layer_out[p->L - 1]), params + p->p_norm_w, params + p->p_norm_b, nullptr, c.at<float>(w.f0),
+                        c.at<float>(w.meanf), c.at<float>(w.rstdf), (int)w.T, p->C, p->CP, nullptr, c.stream));
+  RUN(srk_launch_nchw_tokens(c.at<float>(w.f0), out, B, p->C, p->CP, H * W, 0, c.stream));
   return SRK_OK;
 }
 
@@ -739,6 +934,43 @@ static WgradParams lin_wgrad(const Ctx& c, const bf16_t* Y, int N, const bf16_t*
   q.Y = Y; q.ldy = N; q.X = X; q.ldx = K; q.M = M; q.N = N; q.K = K;
   q.dW = c.at<float>(c.p->ws.gstage_w) + Woff; q.ldw = K; q.db = c.at<float>(c.p->ws.gstage_side) + boff;
   return q;
+}
+
+// weight gradients + input gradient of an RSTB conv / conv_after_body.  gy: bf16 [T][CP] gradient of the conv output, xin: the
+// conv's bf16 input; the input gradient leaves through `gout` with epilogue `ep_out` (its A / Wt / shape fields are set here).
+static int resi_backward(const Ctx& c, const ResiW& rw, const ResiAct& ra, const bf16_t* gy, const bf16_t* xin, int ep_out,
+                         GemmParams gout, int B, int H, int W) {
+  const srk_swinir_plan* p = c.p;
+  const int T = B * H * W, CP = p->CP;
+  hipStream_t st = c.stream;
+  const bf16_t* g_in = gy;          // gradient w.r.t. the output of the first conv
+  const ConvW* first = &rw.c;
+  if (rw.three) {
+    const Workspace& w = p->ws;
+    RUN(conv_wgrad(c, rw.c2, gy, c.at<bf16_t>(ra.a2), B, H, W, 1));
+    {  // through conv .4 and the LeakyReLU in front of it
+      GemmParams g = {};
+      g.A = gy; g.Wt = c.packed + rw.c2.WcT; g.M = T; g.N = 64; g.K = 9 * CP; g.B = B; g.H = H; g.W = W; g.CinP = CP;
+      g.outb = c.at<bf16_t>(w.g3a); g.aux = c.at<bf16_t>(ra.a2); g.scale = 0.2f; g.ldo = 64;
+      g.flops = 2.0 * T * rw.c2.Cout * rw.c2.Cin * 9;
+      RUN(srk_launch_gemm(LD_CONV3, EP_DLRELU, g, st));
+    }
+    {  // the 1x1 conv: weight gradient, then through it and the first LeakyReLU
+      WgradParams q = lin_wgrad(c, c.at<bf16_t>(w.g3a), 64, c.at<bf16_t>(ra.a1), 64, T, rw.W1, rw.b1s, 2.0 * T * rw.C4 * rw.C4);
+      RUN(srk_launch_wgrad(q, st));
+      GemmParams g = {};
+      g.A = c.at<bf16_t>(w.g3a); g.lda = 64; g.Wt = c.packed + rw.W1T; g.M = T; g.N = 64; g.K = 64;
+      g.outb = c.at<bf16_t>(w.g3b); g.aux = c.at<bf16_t>(ra.a1); g.scale = 0.2f; g.ldo = 64; g.flops = 2.0 * T * rw.C4 * rw.C4;
+      RUN(srk_launch_gemm(LD_ROWS, EP_DLRELU, g, st));
+    }
+    g_in = c.at<bf16_t>(w.g3b);
+    first = &rw.c0;
+  }
+  RUN(conv_wgrad(c, *first, g_in, xin, B, H, W, 1));
+  GemmParams g = gout;
+  g.A = g_in; g.Wt = c.packed + first->WcT; g.M = T; g.N = CP; g.K = 9 * first->NP; g.B = B; g.H = H; g.W = W; g.CinP = first->NP;
+  g.ldo = CP; g.flops = 2.0 * T * first->Cout * first->Cin * 9;
+  return srk_launch_gemm(LD_CONV3, ep_out, g, st);
 }
 
 int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* packed, float* grads, const float* d_y,
@@ -812,7 +1044,51 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         g.A = c.at<bf16_t>(w.gt1); g.Wt = c.packed + cb.WcT; g.M = T; g.N = CP; g.K = 9 * 64; g.B = B; g.H = H; g.W = W; g.CinP = 64;
         g.outb = c.at<bf16_t>(w.gfb); g.ldo = CP; g.flops = 2.0 * T * cb.Cout * cb.Cin * 9;
         RUN(srk_launch_gemm(LD_CONV3, EP_BF16, g, st));
+      } else if (p->cfg.upsampler == SRK_UPSAMPLER_NEAREST_CONV) {
+        int hs = H, wsz = W;
+        for (int k = 0; k < p->nstage; ++k) { hs *= 2; wsz *= 2; }
+        const long long out_px = (long long)B * hs * wsz;
+        RUN(srk_launch_img_grad_prep(d_y, c.at<float>(w.gyimg), B, p->Cimg, H0 * s, W0 * s, hs, wsz, 1, 4, inv_range, st));
+        const ConvW& cl = p->conv_last;
+        bf16_t* gA = c.at<bf16_t>(w.ncgA);
+        bf16_t* gB = c.at<bf16_t>(w.ncgB);
+        bf16_t* gU = c.at<bf16_t>(w.ncgU);
+        RUN(srk_launch_smallconv_wgrad(c.at<bf16_t>(w.nc_hr), c.at<float>(w.gyimg), grads + cl.w, grads + cl.b, B, hs, wsz, 64, 64,
+                                       p->Cimg, 4, st));
+        RUN(srk_launch_smallconv_dgrad(c.at<float>(w.gyimg), params + cl.w, gA, B, hs, wsz, 64, 64, p->Cimg, 4, st));
+        RUN(srk_launch_dlrelu_bf16(gA, c.at<bf16_t>(w.nc_hr), 0.2f, out_px * 64, st));        // through lrelu(conv_hr)
+        {
+          const ConvW& ch = p->conv_hr;
+          const bf16_t* x_hr = c.at<bf16_t>(w.nc_a[p->nstage - 1]);
+          RUN(conv_wgrad(c, ch, gA, x_hr, B, hs, wsz, 1));
+          GemmParams g = {};
+          g.A = gA; g.Wt = c.packed + ch.WcT; g.M = (int)out_px; g.N = 64; g.K = 9 * 64; g.B = B; g.H = hs; g.W = wsz; g.CinP = 64;
+          g.outb = gB; g.aux = x_hr; g.scale = 0.2f; g.ldo = 64; g.flops = 2.0 * out_px * 64 * 64 * 9;
+          RUN(srk_launch_gemm(LD_CONV3, EP_DLRELU, g, st));                                  // ... and lrelu(conv_up_last)
+        }
+        for (int k = p->nstage - 1; k >= 0; --k) {
+          const ConvW& cw = p->up_convs[k];
+          const long long px = (long long)B * hs * wsz;
+          RUN(conv_wgrad(c, cw, gB, c.at<bf16_t>(w.nc_u[k]), B, hs, wsz, 1));
+          GemmParams g = {};
+          g.A = gB; g.Wt = c.packed + cw.WcT; g.M = (int)px; g.N = 64; g.K = 9 * 64; g.B = B; g.H = hs; g.W = wsz; g.CinP = 64;
+          g.outb = gU; g.ldo = 64; g.flops = 2.0 * px * 64 * 64 * 9;
+          RUN(srk_launch_gemm(LD_CONV3, EP_BF16, g, st));                                    // gradient of the upsampled tensor
+          hs /= 2;
+          wsz /= 2;
+          // sum over the 2x2 children + the LeakyReLU of the tensor that was upsampled (t1: slope 0.01, conv_up1 output: 0.2)
+          const bf16_t* act = k == 0 ? c.at<bf16_t>(w.t1) : c.at<bf16_t>(w.nc_a[k - 1]);
+          bf16_t* dst = k == 0 ? c.at<bf16_t>(w.gt1) : gB;
+          RUN(srk_launch_nn2x_sum_dlrelu(gU, act, dst, B, hs, wsz, 64, k == 0 ? 0.01f : 0.2f, st));
+        }
+        const ConvW& cb = p->conv_before_up;
+        RUN(conv_wgrad(c, cb, c.at<bf16_t>(w.gt1), c.at<bf16_t>(w.fb), B, H, W, 1));
+        GemmParams g = {};
+        g.A = c.at<bf16_t>(w.gt1); g.Wt = c.packed + cb.WcT; g.M = T; g.N = CP; g.K = 9 * 64; g.B = B; g.H = H; g.W = W; g.CinP = 64;
+        g.outb = c.at<bf16_t>(w.gfb); g.ldo = CP; g.flops = 2.0 * T * cb.Cout * cb.Cin * 9;
+        RUN(srk_launch_gemm(LD_CONV3, EP_BF16, g, st));
       } else {
+        // 'pixelshuffledirect' (s*s*in_chans output channels) and the denoising head (s == 1; its "+ x" has no parameters)
         const ConvW& cu = p->up_direct;
         RUN(srk_launch_img_grad_prep(d_y, c.at<float>(w.gyimg), B, p->Cimg, H0 * s, W0 * s, H, W, s, 16, inv_range, st));
         RUN(srk_launch_smallconv_wgrad(c.at<bf16_t>(w.fb), c.at<float>(w.gyimg), grads + cu.w, grads + cu.b, B, H, W, C, CP,
@@ -820,13 +1096,10 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         RUN(srk_launch_smallconv_dgrad(c.at<float>(w.gyimg), params + cu.w, c.at<bf16_t>(w.gfb), B, H, W, C, CP, cu.Cout, 16, st));
       }
       // conv_after_body (gfb also feeds the long skip into f0, consumed by the head segment)
-      const ConvW& ca = p->conv_after_body;
-      RUN(conv_wgrad(c, ca, c.at<bf16_t>(w.gfb), c.at<bf16_t>(w.xnf), B, H, W, 1));
       {
         GemmParams g = {};
-        g.A = c.at<bf16_t>(w.gfb); g.Wt = c.packed + ca.WcT; g.M = T; g.N = CP; g.K = 9 * CP; g.B = B; g.H = H; g.W = W; g.CinP = CP;
-        g.outb = c.at<bf16_t>(w.dxn); g.ldo = CP; g.flops = 2.0 * T * ca.Cout * ca.Cin * 9;
-        RUN(srk_launch_gemm(LD_CONV3, EP_BF16, g, st));
+        g.outb = c.at<bf16_t>(w.dxn);
+        RUN(resi_backward(c, p->conv_after_body, w.resi[p->L], c.at<bf16_t>(w.gfb), c.at<bf16_t>(w.xnf), EP_BF16, g, B, H, W));
       }
       // final norm
       RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(w.layer_out[p->L - 1]), c.at<float>(w.meanf), c.at<float>(w.rstdf),
@@ -837,16 +1110,12 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
       // ---------------- RSTB l ----------------
       const int l = p->L - seg;
       const int first = p->layer_first_blk[l], depth = p->cfg.depths[l];
-      const ConvW& cw = p->layer_conv[l];
-      RUN(conv_wgrad(c, cw, c.at<bf16_t>(w.gxb), c.at<bf16_t>(w.layer_xb[l]), B, H, W, 1));
       {
         const int last = first + depth - 1;
         GemmParams g = {};
-        g.A = c.at<bf16_t>(w.gxb); g.Wt = c.packed + cw.WcT; g.M = T; g.N = CP; g.K = 9 * CP; g.B = B; g.H = H; g.W = W; g.CinP = CP;
-        g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxb2); g.ldo = CP;
+        g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxb2);
         g.rowscale = drop_scale ? drop_scale + ((size_t)last * 2 + 1) * B : nullptr; g.rows_per_sample = HW;
-        g.flops = 2.0 * T * cw.Cout * cw.Cin * 9;
-        RUN(srk_launch_gemm(LD_CONV3, EP_F32_BF16, g, st));
+        RUN(resi_backward(c, p->layer_conv[l], w.resi[l], c.at<bf16_t>(w.gxb), c.at<bf16_t>(w.layer_xb[l]), EP_F32_BF16, g, B, H, W));
       }
       for (int j = depth - 1; j >= 0; --j) {
         const int bi = first + j;

@@ -30,13 +30,11 @@ class SwinIRPlan:
 
     def __init__(self, *, img_size: int, in_chans: int, embed_dim: int, depths: Sequence[int], num_heads: Sequence[int],
                  window_size: int, mlp_ratio: float, upscale: int, img_range: float, upsampler: str,
-                 qk_scale: Optional[float] = None):
-        if upsampler == "pixelshuffle":
-            ups = _lib.UPSAMPLER_PIXELSHUFFLE
-        elif upsampler == "pixelshuffledirect":
-            ups = _lib.UPSAMPLER_PIXELSHUFFLEDIRECT
-        else:
-            raise _lib.SrkUnsupported(f"HIP path supports upsampler 'pixelshuffle' / 'pixelshuffledirect' (got {upsampler!r})")
+                 qk_scale: Optional[float] = None, resi_connection: str = "1conv"):
+        # any other upsampler string takes the reference's `else` branch: the denoising head (network_swinir.py:760-762)
+        ups = _lib.UPSAMPLERS.get(upsampler, _lib.UPSAMPLER_NONE)
+        if resi_connection not in _lib.RESI:
+            raise ValueError(f"unknown resi_connection {resi_connection!r}")
         if len(depths) != len(num_heads) or len(depths) > 16:
             raise ValueError("depths / num_heads must have the same length (<= 16)")
         cfg = SwinIRConfig()
@@ -56,6 +54,7 @@ class SwinIRPlan:
         for i in range(3):
             cfg.mean[i] = mean[i]
         cfg.qk_scale = float(qk_scale) if qk_scale else 0.0
+        cfg.resi_connection = _lib.RESI[resi_connection]
         self.cfg = cfg
         self.upscale = int(upscale)
         self.n_blocks = int(sum(depths))
@@ -156,6 +155,23 @@ class SwinIREngine:
             check(lib().srk_swinir_forward(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), x.data_ptr(),
                                            y.data_ptr(), ws.data_ptr(), B, H, W, int(training), ds, _stream(self.device)))
         return y
+
+    def forward_features(self, f: torch.Tensor) -> torch.Tensor:
+        """SwinIR.forward_features (network_swinir.py:790-803): conv_first output [B,C,H,W] -> [B,C,H,W]; inference only."""
+        if not f.is_cuda or f.device != self.device:
+            raise RuntimeError(f"forward_features needs a tensor on {self.device} (no CPU fallback in this package)")
+        f = f.contiguous().float()
+        B, Cc, H, W = f.shape
+        if Cc != self.plan.cfg.embed_dim:
+            raise ValueError(f"expected {self.plan.cfg.embed_dim} feature channels, got {Cc}")
+        if not self.packed_valid:
+            self.pack()
+        ws = self._workspace(B, H, W, False)
+        out = torch.empty_like(f)
+        with torch.cuda.device(self.device):
+            check(lib().srk_swinir_forward_features(self.plan.handle, self.flat.data_ptr(), self.packed.data_ptr(), f.data_ptr(),
+                                                    out.data_ptr(), ws.data_ptr(), B, H, W, _stream(self.device)))
+        return out
 
     def backward(self, d_y: torch.Tensor, shape: Tuple[int, int, int], drop_scale: Optional[torch.Tensor] = None) -> None:
         """Accumulates parameter gradients into flat_grad; calls segment_hook(seg, begin, end) after each segment."""

@@ -8,10 +8,11 @@ the parameters; the arithmetic of ``SwinIR.forward`` and its backward run in han
 kernels behind the C ABI of ``include/srk.h``.  There is no CPU path: a CPU tensor, a missing
 ``libsrk.so`` or a configuration the kernels do not cover raises.
 
-Covered by the HIP path: window_size 8, head_dim <= 32, embed_dim <= 256, in_chans 1/3,
-resi_connection '1conv', patch_norm=True, ape=False, upsampler 'pixelshuffle' (x2/x3/x4/x8) and
-'pixelshuffledirect' (upscale^2 * in_chans <= 16).  Other constructor options build the same
-state_dict but raise ``NotImplementedError`` in ``forward``.
+Covered by the HIP path: window_size 8, head_dim <= 32, embed_dim <= 256, in_chans 1/3, resi_connection '1conv' and
+'3conv', patch_norm=True, ape=False, all four heads -- 'pixelshuffle' (x2/x3/x4/x8), 'pixelshuffledirect'
+(upscale^2 * in_chans <= 16), 'nearest+conv' (x2/x4) and '' (denoising, upscale 1) -- and ``forward_features`` as a callable
+(inference).  Other constructor options (window_size != 8, ape, patch_norm=False, dropout > 0) build the same state_dict but
+raise ``NotImplementedError`` in ``forward``.
 """
 from __future__ import annotations
 
@@ -319,8 +320,6 @@ class SwinIR(nn.Module):
             return "ape=True"
         if not self.patch_norm:
             return "patch_norm=False"
-        if self.resi_connection != '1conv':
-            return f"resi_connection={self.resi_connection!r}"
         if not self.qkv_bias:
             return "qkv_bias=False"
         if self.patch_size != 1:
@@ -339,7 +338,7 @@ class SwinIR(nn.Module):
             self._plan = SwinIRPlan(img_size=min(self.patches_resolution), in_chans=self.in_chans, embed_dim=self.embed_dim,
                                     depths=self.depths, num_heads=self.heads, window_size=self.window_size,
                                     mlp_ratio=self.mlp_ratio, upscale=self.upscale, img_range=self.img_range,
-                                    upsampler=self.upsampler, qk_scale=self.qk_scale)
+                                    upsampler=self.upsampler, qk_scale=self.qk_scale, resi_connection=self.resi_connection)
         eng = SwinIREngine(self._plan, device)
         named = dict(self.named_parameters())
         missing = [p.name for p in self._plan.params if p.name not in named]
@@ -389,7 +388,24 @@ class SwinIR(nn.Module):
 
     # -- forward ----------------------------------------------------------------------------------------------
     def forward_features(self, x):
-        raise NotImplementedError("forward_features is fused into SwinIR.forward on the HIP path")
+        """network_swinir.py:790-803 as a callable: x = conv_first's output [B, embed_dim, H, W] (H, W multiples of the
+        window size) -> patch_embed norm -> RSTBs -> norm -> [B, embed_dim, H, W].  ``forward`` does not call this (the
+        executor runs the same kernels inside one fused sequence); it exists for code that uses the method directly.
+        Inference only: no autograd graph is recorded."""
+        if not x.is_cuda:
+            raise RuntimeError("this SwinIR runs on MI355X through libsrk only (no CPU fallback exists in this package)")
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+            raise RuntimeError("forward_features on the HIP path is inference-only; call it under torch.no_grad() / in eval mode "
+                               "(training goes through SwinIR.forward)")
+        eng = self._bind(x.device)
+        if not self._param_views_ok(eng):
+            self._engine = None
+            eng = self._bind(x.device)
+        ver = sum(p._version for p in self.parameters())
+        if ver != eng.pack_version:
+            eng.packed_valid = False
+            eng.pack_version = ver
+        return eng.forward_features(x)
 
     def forward(self, x, drop_scale: Optional[torch.Tensor] = None):
         if not x.is_cuda:
