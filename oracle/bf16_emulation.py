@@ -147,9 +147,19 @@ class _GeluFromStoredU(torch.autograd.Function):
         return g * (cdf + ub * pdf)
 
 
+def resi_conv_emul(x_q: Tensor, sd: Dict[str, Tensor], name: str, kind: str) -> Tensor:
+    """'1conv' / '3conv' residual-connection conv as the executor runs it (csrc/swinir.hip resi_forward): every conv reads a
+    bf16 activation and bf16 weights; the two narrow LeakyReLU(0.2) outputs are stored in bf16."""
+    if kind == "1conv":
+        return qconv(x_q, sd[name + ".weight"], sd[name + ".bias"])
+    a1 = rnd(F.leaky_relu(qconv(x_q, sd[name + ".0.weight"], sd[name + ".0.bias"]), 0.2))
+    a2 = rnd(F.leaky_relu(grnd(F.conv2d(a1, rnd(sd[name + ".2.weight"]), sd[name + ".2.bias"])), 0.2))
+    return qconv(a2, sd[name + ".4.weight"], sd[name + ".4.bias"])
+
+
 def swinir_forward_emul(sd: Dict[str, Tensor], cfg: O.SwinIRConfig, x: Tensor, drop_keep: Optional[Tensor] = None) -> Tensor:
     """HIP-pipeline emulation of SwinIR.forward for the heads the HIP path covers."""
-    assert cfg.window_size == 8 and cfg.resi_connection == "1conv" and cfg.upsampler in ("pixelshuffle", "pixelshuffledirect")
+    assert cfg.window_size == 8
     H0, W0 = x.shape[2:]
     ph, pw = (8 - H0 % 8) % 8, (8 - W0 % 8) % 8
     if ph or pw:
@@ -173,11 +183,11 @@ def swinir_forward_emul(sd: Dict[str, Tensor], cfg: O.SwinIRConfig, x: Tensor, d
             y = emul_block(y, H, W, sd, f"layers.{li}.residual_group.blocks.{bi}.", cfg.num_heads[li], shift, fa, fm, cfg.qk_scale)
             blk += 1
         yb = rnd(y).transpose(1, 2).reshape(B, C, H, W)                                  # bf16 copy feeds the RSTB conv
-        cv = qconv(yb, sd[f"layers.{li}.conv.weight"], sd[f"layers.{li}.conv.bias"])
+        cv = resi_conv_emul(yb, sd, f"layers.{li}.conv", cfg.resi_connection)
         t = cv.flatten(2).transpose(1, 2) + t
     # the final LayerNorm's backward reads a bf16 dy (dxn)
     xn = rnd(grnd(F.layer_norm(t, (C,), sd["norm.weight"], sd["norm.bias"], 1e-5))).transpose(1, 2).reshape(B, C, H, W)
-    fb = rnd(qconv(xn, sd["conv_after_body.weight"], sd["conv_after_body.bias"]) + grnd(f0))
+    fb = rnd(resi_conv_emul(xn, sd, "conv_after_body", cfg.resi_connection) + grnd(f0))
     s = cfg.upscale
     if cfg.upsampler == "pixelshuffle":
         f = rnd(F.leaky_relu(qconv(fb, sd["conv_before_upsample.0.weight"], sd["conv_before_upsample.0.bias"]), 0.01))
@@ -186,8 +196,18 @@ def swinir_forward_emul(sd: Dict[str, Tensor], cfg: O.SwinIRConfig, x: Tensor, d
         for i in range(stages):
             f = rnd(O.pixel_shuffle(qconv(f, sd[f"upsample.{2 * i}.weight"], sd[f"upsample.{2 * i}.bias"]), r))
         out = _ConvLast.apply(f, sd["conv_last.weight"], sd["conv_last.bias"])
-    else:
+    elif cfg.upsampler == "pixelshuffledirect":
         out = O.pixel_shuffle(_ConvLast.apply(fb, sd["upsample.0.weight"], sd["upsample.0.bias"]), s)
+    elif cfg.upsampler == "nearest+conv":
+        f = rnd(F.leaky_relu(qconv(fb, sd["conv_before_upsample.0.weight"], sd["conv_before_upsample.0.bias"]), 0.01))
+        for name in (("conv_up1", "conv_up2") if s == 4 else ("conv_up1",)):
+            # the 2x2 sum of the upsample's backward is formed in fp32 and rounded once, with the LeakyReLU factor applied
+            f = rnd(F.leaky_relu(qconv(grnd(F.interpolate(f, scale_factor=2, mode="nearest")), sd[name + ".weight"],
+                                       sd[name + ".bias"]), 0.2))
+        f = rnd(F.leaky_relu(qconv(f, sd["conv_hr.weight"], sd["conv_hr.bias"]), 0.2))
+        out = _ConvLast.apply(f, sd["conv_last.weight"], sd["conv_last.bias"])
+    else:
+        out = x + _ConvLast.apply(fb, sd["conv_last.weight"], sd["conv_last.bias"])
     out = out / cfg.img_range + mean
     return out[:, :, :H0 * s, :W0 * s]
 
