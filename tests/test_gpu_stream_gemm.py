@@ -270,3 +270,44 @@ def test_wgrad_workspace_is_the_callers_and_optional(ops):
     for got in (a1, a2, b1):
         assert float((got - ref).abs().max()) < tol
     assert torch.equal(b1, b2)
+
+
+@pytest.mark.parametrize("bs,drop", [(4, False), (5, True)])       # 16384 rows (one 16-row tile list per CU) / uneven lists + DropPath
+def test_fused_mlp_matches_separate_fc1_fc2_kernels(bs, drop):
+    """csrc/gemm_stream.hip mlp_fused_fwd_kernel (fc1 + GELU + fc2 + residual + next LayerNorm, hidden tile in LDS) against the
+    fc1 / fc2 streaming GEMMs: same MFMA order and rounding points -> bit-identical outputs in training and in inference; the
+    backward pass consumes the u / h tensors the fused kernel stored."""
+    from tpu_superresolution_amd._lib import check, lib
+    cfg = _mid_cfg()
+    sd = O.random_state_dict(cfg, seed=13, scale=1.0)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(bs, 3, 64, 64, generator=gen).cuda()
+    t = torch.rand(bs, 3, 128, 128, generator=gen).cuda()
+    ds = None
+    if drop:
+        keep = 1.0 - torch.linspace(0, 0.3, 4).view(4, 1, 1)
+        ds = ((torch.rand(4, 2, bs, generator=gen) < keep).float() / keep).cuda()
+    res = {}
+    try:
+        for on in (1, 0):
+            check(lib().srk_set_option(b"mlp_fused", on))
+            m = build(cfg, sd, train=True, drop_path_rate=0.3 if drop else 0.0)
+            out = m(x, drop_scale=ds)
+            torch.nn.functional.l1_loss(out, t).backward()
+            torch.cuda.synchronize()
+            u = m._engine.activation("blk1.u", torch.bfloat16).clone()
+            h = m._engine.activation("blk1.h", torch.bfloat16).clone()
+            m.eval()
+            with torch.no_grad():
+                y_inf = m(x).clone()
+            res[on] = (out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}, u.cpu(), h.cpu(), y_inf.cpu())
+    finally:
+        check(lib().srk_set_option(b"mlp_fused", 1))
+    assert torch.isfinite(res[1][0]).all()
+    assert torch.equal(res[1][2].view(torch.int16), res[0][2].view(torch.int16)), "u differs"
+    assert torch.equal(res[1][3].view(torch.int16), res[0][3].view(torch.int16)), "h differs"
+    assert torch.equal(res[1][0], res[0][0]), float((res[1][0] - res[0][0]).abs().max())
+    assert torch.equal(res[1][4], res[0][4])
+    for n in res[0][1]:
+        rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
+        assert rel <= 1e-4, f"{n}: {rel:.3e}"            # bias / LayerNorm gradients use fp32 atomics (order-dependent last bits)

@@ -253,6 +253,10 @@ int srk_set_option(const char* name, int value) {
     srk_attn_fused_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "mlp_fused") == 0) {
+    srk_mlp_fused_enable(value);
+    return SRK_OK;
+  }
   if (strcmp(name, "probe_stride") == 0) {
     SRK_REQUIRE(value >= 1 && value <= 1024, SRK_E_SHAPE, "probe_stride: 1..1024");
     g_probe.stride = value;

@@ -78,6 +78,13 @@ struct GemmParams {
   const float* xn_beta;
   int xn_C, xn_window;
   WinGeom xn_geom;
+  // fused MLP (srk_launch_mlp_fused): A = xn2 [M][lda], Wt = fc1 weights [HP][K], bias = fc1 bias [HP]; second layer below;
+  // res / outf / outb / rowscale / xn_* as for EP_RES (the fc2 + residual epilogue)
+  const bf16_t* W2;       // fc2 weights [N][HP] bf16
+  const float* bias2;     // [N]
+  bf16_t* u_out;          // [M][HP] pre-activation (training: read by the backward pass) or null
+  bf16_t* h_out;          // [M][HP] gelu(u)         (training: operand of the fc2 weight gradient) or null
+  int HP;                 // hidden width (padded), 384
 };
 
 int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t stream);
@@ -87,3 +94,7 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
 int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream);
 void srk_gemm_stream_enable(int on);
 void srk_gemm_stream_tune(int bm, int ks2, int split, int nb);   // 0 / -1 / -1 / 0: defaults
+// Mlp.forward + residual (+ the next LayerNorm) as ONE persistent kernel: out = res + rowscale * (gelu(A W1^T + b1) W2^T + b2),
+// the 16 x 384 hidden tile stays in LDS.  C = 180 (192 padded), hidden 360 (384).  SRK_NOT_COVERED -> run fc1 / fc2 separately.
+int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream);
+void srk_mlp_fused_enable(int on);

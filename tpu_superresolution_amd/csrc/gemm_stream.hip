@@ -739,6 +739,214 @@ __global__ __launch_bounds__(64 * (NB + 4)) void gemm_stream_split_kernel(const 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused MLP forward: x_out = x1 + f * (gelu(xn2 W1^T + b1) W2^T + b2)  [+ bf16 copy, + the next LayerNorm]
+// (network_swinir.py:25-28 Mlp.forward and the second residual of SwinTransformerBlock.forward :277)
+//
+// One persistent 512-thread workgroup per CU walks 16-row tiles.  The two weight matrices live in registers for the whole
+// kernel: the FRONT waves (4-7) each hold a 96-column slice of W1 (6 x 6 fragments), the BACK waves (0-3) each a 48-column
+// slice of W2 over the full K = 384 (3 x 12 fragments).  Per tile:
+//   front  DMA ring (xn2 rows, fp32 residual rows, row scalars / maps -- the EP_RES loader of the streaming GEMM) ->
+//          fc1 MFMA -> bias + GELU in registers (MFMA layout) -> u and h = gelu(u) as bf16 into the double-buffered LDS
+//          tiles Us / Hs (swizzled A-operand layout of fc2); the front waves never store to global memory, so their counted
+//          vmcnt waits see only DMAs;
+//   back   fc2 MFMA from Hs -> T2 -> the row-major fc2 epilogue of the streaming GEMM (bias, DropPath factor, residual,
+//          fp32 / bf16 stores, fused LayerNorm of the new row) and, when training, the coalesced global stores of the u / h
+//          rows from LDS (both are only read by the backward pass: nt stores).
+// Two barriers per iteration; in iteration i the front works on tile i while the back finishes tiles i-1 (fc2) and i-2
+// (epilogue), so MFMA, GELU VALU work, LDS traffic and the global stores of three tiles overlap on every SIMD.  The hidden
+// activations never travel to HBM between fc1 and fc2 (inference: they never leave the CU at all).  Same MFMA order and
+// rounding points as the separate fc1 / fc2 kernels: results are bit-identical to them.
+// ------------------------------------------------------------------------------------------------
+struct MlpCfg {
+  using C = StreamCfg<EP_RES, 3, 16>;
+  static constexpr int BM = 16, K1 = 192, HP = 384, R = 5;
+  static constexpr int T2_OFF = 0;
+  static constexpr int B1_OFF = C::T_BYTES;                 // [3][192] fp32: fc2 bias, gamma / beta of the fused LayerNorm (zero-padded)
+  static constexpr int UH_BYTES = BM * HP * 2;              // one bf16 [16][384] tile
+  static constexpr int US_OFF = B1_OFF + 3 * SBN * 4;       // Us[2], Hs[2]: double-buffered (front writes tile i while the back reads i-1)
+  static constexpr int HS_OFF = US_OFF + 2 * UH_BYTES;
+  static constexpr int SLOTS_OFF = HS_OFF + 2 * UH_BYTES;
+  static constexpr int LDS = SLOTS_OFF + R * C::SLOT;
+  static_assert(LDS <= LDS_BUDGET, "fused MLP: LDS budget");
+  static_assert(C::P * (R - 4) <= 63, "vmcnt overflow");
+};
+
+__global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(const GemmParams p, int groups_per_xcd) {
+  using M = MlpCfg;
+  using C = M::C;
+  constexpr int R = M::R, BM = M::BM;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  float* T2 = reinterpret_cast<float*>(smem + M::T2_OFF);
+  float* b1s = reinterpret_cast<float*>(smem + M::B1_OFF);
+  unsigned char* Us = smem + M::US_OFF;
+  unsigned char* Hs = smem + M::HS_OFF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, gx = blockIdx.x >> 3;
+  if (gx >= groups_per_xcd) return;
+  const int Gm = 8 * groups_per_xcd, gi = gx * 8 + xcd;
+  const int ntm = p.M / BM;
+  const int nt = gi < ntm ? (ntm - gi + Gm - 1) / Gm : 0;
+  if (nt == 0) return;
+  // row vectors of the back waves' epilogue live in LDS (W2 fills their registers): fc2 bias | LayerNorm gamma | beta
+  for (int i = tid; i < 3 * SBN; i += 512) {
+    const int which = i / SBN, n = i - which * SBN;
+    float v = 0.f;
+    if (which == 0) v = p.bias2 ? p.bias2[n] : 0.f;
+    else if (p.xn_out && n < p.xn_C) v = which == 1 ? p.xn_gamma[n] : p.xn_beta[n];
+    b1s[i] = v;
+  }
+  __syncthreads();
+
+  if (wave >= 4) {
+    // =================================== front waves: DMA + fc1 + GELU ===============================
+    const int lw = wave - 4;
+    bf16x8_t wf[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int s = 0; s < 6; ++s)
+        wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(lw * 96 + 16 * j + r16) * M::K1 + s * 32 + g * 8);
+    float4 b1[6];                                                       // fc1 bias of this lane's columns
+#pragma unroll
+    for (int j = 0; j < 6; ++j) b1[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + lw * 96 + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+      for (int s = 0; s < 6; ++s) asm volatile("" ::"v"(wf[j][s]));     // retire the loads before the DMA ring starts
+      asm volatile("" ::"v"(b1[j].x), "v"(b1[j].y), "v"(b1[j].z), "v"(b1[j].w));
+    }
+
+    IssueState<EP_RES, 3, BM> is;
+    issue_init<EP_RES, 3, BM>(p, 0, lw, lane, is);
+    for (int s = 0; s < R - 3 && s < nt; ++s)
+      stream_issue_tile<EP_RES, 3, BM>(p, is, (gi + s * Gm) * BM, 0, smem_base + M::SLOTS_OFF + s * C::SLOT, lw, lane, smem, smem_base);
+    for (int i = 0; i < nt + 2; ++i) {
+      if (i < nt) {
+        // tile i has landed once at most the R-4 tiles issued after it are outstanding
+        if (i + R - 4 < nt) wait_vmcnt<C::P*(R - 4)>(); else wait_vmcnt<0>();
+      }
+      lds_barrier();                                            // A(i)
+      if (i < nt) {
+        if (i + R - 3 < nt)
+          stream_issue_tile<EP_RES, 3, BM>(p, is, (gi + (i + R - 3) * Gm) * BM, 0, smem_base + M::SLOTS_OFF + ((i + R - 3) % R) * C::SLOT, lw,
+                                           lane, smem, smem_base);
+        const unsigned char* slot = smem + M::SLOTS_OFF + (i % R) * C::SLOT;
+        f32x4_t acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(slot + r16 * (M::K1 * 2) + (((s * 4 + g) ^ (r16 & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+        }
+        // lane holds u[row r16][n .. n+3], n = 96 lw + 16 j + 4 g  ->  bias, GELU, bf16 into this tile's Us / Hs
+        unsigned char* us = Us + (i & 1) * M::UH_BYTES;
+        unsigned char* hs = Hs + (i & 1) * M::UH_BYTES;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float4 bv = b1[j];
+          const float v0 = acc[j][0] + bv.x, v1 = acc[j][1] + bv.y, v2 = acc[j][2] + bv.z, v3 = acc[j][3] + bv.w;
+          const int n = lw * 96 + 16 * j + 4 * g;               // 16-byte chunk n / 8, half (n & 4)
+          const int off = r16 * (M::HP * 2) + ((((n >> 3) ^ (r16 & 7)) << 4) | ((n & 4) << 1));
+          *reinterpret_cast<uint2*>(us + off) = pack_bf4(v0, v1, v2, v3);
+          *reinterpret_cast<uint2*>(hs + off) = gelu_pack4(v0, v1, v2, v3);
+        }
+      }
+      lds_barrier();                                            // B(i): (back-wave hand-over of T2)
+    }
+  } else {
+    // =================================== back waves: fc2 + row epilogue + stores ======================
+    const int wn = wave;
+    bf16x8_t w2[3][12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < 12; ++s)
+        w2[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W2 + (long long)(wn * 48 + 16 * j + r16) * M::HP + s * 32 + g * 8);
+    const int btid = tid;        // 0..255
+    const int sub = lane >> 4, j16 = lane & 15, lr = wave * 4 + sub;     // row epilogue: 16 lanes per row, 4 rows per wave
+    const bool has_scale = p.rowscale != nullptr;
+    for (int i = 0; i < nt + 2; ++i) {
+      lds_barrier();                                            // A(i)
+      if (i >= 2) {                                             // fc2 epilogue of tile i-2 (T2 holds it since B(i-1))
+        const int t = i - 2;
+        const unsigned char* slot = smem + M::SLOTS_OFF + (t % R) * C::SLOT;
+        const unsigned char* e0 = slot + C::A_BYTES;                    // fp32 residual rows of the tile
+        const float* auxf = reinterpret_cast<const float*>(slot + C::A_BYTES + C::E32_BYTES);
+        const int* maps = reinterpret_cast<const int*>(auxf + 4 * 64);
+        const long long t_ = maps[lr];
+        const float f = has_scale ? auxf[lr] : 1.0f;
+        float4 o[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 v = *reinterpret_cast<const float4*>(T2 + lr * SBNP + 64 * c + 4 * j16);
+          const float4 bv = *reinterpret_cast<const float4*>(b1s + 64 * c + 4 * j16);
+          const float4 rv = *reinterpret_cast<const float4*>(e0 + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+          o[c] = make_float4(rv.x + (v.x + bv.x) * f, rv.y + (v.y + bv.y) * f, rv.z + (v.z + bv.z) * f, rv.w + (v.w + bv.w) * f);
+          st_f4(p.outf + t_ * p.ldo + 64 * c + 4 * j16, o[c]);
+          if (p.outb) st_u2(p.outb + t_ * p.ldo + 64 * c + 4 * j16, pack_bf4(o[c].x, o[c].y, o[c].z, o[c].w));
+        }
+        if (p.xn_out) {
+          float lg[NC][4], lb[NC][4];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float4 gv = *reinterpret_cast<const float4*>(b1s + SBN + 64 * c + 4 * j16);
+            const float4 bb = *reinterpret_cast<const float4*>(b1s + 2 * SBN + 64 * c + 4 * j16);
+            lg[c][0] = gv.x; lg[c][1] = gv.y; lg[c][2] = gv.z; lg[c][3] = gv.w;
+            lb[c][0] = bb.x; lb[c][1] = bb.y; lb[c][2] = bb.z; lb[c][3] = bb.w;
+          }
+          fused_ln_row_at<NC>(p, o, maps[64 + lr], j16, lg, lb);
+        }
+      }
+      f32x4_t acc[3];
+      const bool have = i >= 1 && i - 1 < nt;
+      if (have) {                                               // fc2 of tile i-1 from Hs
+        const unsigned char* us = Us + ((i - 1) & 1) * M::UH_BYTES;
+        const unsigned char* hs = Hs + ((i - 1) & 1) * M::UH_BYTES;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(hs + r16 * (M::HP * 2) + (((s * 4 + g) ^ (r16 & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][s], xf, acc[j], 0, 0, 0);
+        }
+        if (p.u_out) {                                          // training: u / h rows leave the CU once, as 768-byte rows
+          const long long m0 = (long long)(gi + (i - 1) * Gm) * BM;
+          int bt = btid;
+          asm volatile("" : "+v"(bt));                          // recompute the chunk map per tile: W2 owns the registers
+#pragma unroll 1
+          for (int it = 0; it < 3; ++it) {
+            const int idx = it * 256 + bt;                      // 16 rows x 48 chunks
+            const int row = idx / 48, c = idx - row * 48;
+            const int off = row * (M::HP * 2) + ((c ^ (row & 7)) << 4);
+            const uint4 uv = *reinterpret_cast<const uint4*>(us + off);
+            const uint4 hv = *reinterpret_cast<const uint4*>(hs + off);
+            typedef unsigned srk_u4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(srk_u4{uv.x, uv.y, uv.z, uv.w}, reinterpret_cast<srk_u4*>(p.u_out + (m0 + row) * p.HP + c * 8));
+            __builtin_nontemporal_store(srk_u4{hv.x, hv.y, hv.z, hv.w}, reinterpret_cast<srk_u4*>(p.h_out + (m0 + row) * p.HP + c * 8));
+          }
+        }
+      }
+      lds_barrier();                                            // B(i): T2's readers (epilogue of tile i-2) are done
+      if (have) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          *reinterpret_cast<float4*>(T2 + r16 * SBNP + wn * 48 + 16 * j + 4 * g) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      }
+    }
+  }
+}
+
+int g_mlp_fused_enabled = 1;
+
 int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
 int g_num_cus = 0;
 int g_tune_bm = 0;             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
@@ -897,4 +1105,34 @@ int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream
       return dispatch_k<EP_LNBWD>(p, stream, {16, true, false}, {16, true, false});
     default: return SRK_NOT_COVERED;
   }
+}
+
+void srk_mlp_fused_enable(int on) { g_mlp_fused_enabled = on ? 1 : 0; }
+
+int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream) {
+  if (!g_mlp_fused_enabled) return SRK_NOT_COVERED;
+  if (g_stream_enabled < 0) {
+    const char* e = getenv("SRK_GEMM_STREAM");
+    g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_stream_enabled) return SRK_NOT_COVERED;
+  if (g_num_cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    g_num_cus = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount & ~7;
+  }
+  if (g_num_cus < 8) return SRK_NOT_COVERED;
+  if (p.K != MlpCfg::K1 || p.HP != MlpCfg::HP || p.N != SBN || p.lda % 8 != 0 || p.ldo != SBN) return SRK_NOT_COVERED;
+  if (p.M % 64 != 0 || p.M < 64 * g_num_cus || p.M >= (1 << 24)) return SRK_NOT_COVERED;
+  if (p.rowscale && (p.rows_per_sample <= 0 || p.rows_per_sample % 64 != 0)) return SRK_NOT_COVERED;
+  if (!p.A || !p.Wt || !p.W2 || !p.res || !p.outf || (p.u_out != nullptr) != (p.h_out != nullptr)) return SRK_NOT_COVERED;
+  static int configured = 0;
+  const int rc = stream_configure(&mlp_fused_fwd_kernel, MlpCfg::LDS, &configured);
+  if (rc) return rc;
+  if (configured < 0) return SRK_NOT_COVERED;       // the build spilled: never run it (scratch traffic would break the counted waits)
+  srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
+  hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(g_num_cus), dim3(512), MlpCfg::LDS, stream, p, g_num_cus / 8);
+  srk_probe_post(FAM_GEMM_LINEAR, stream);
+  return srk_check_launch("mlp_fused");
 }

@@ -749,15 +749,12 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
       if (!fuse_ln)   // LN2                           :277
         RUN(srk_launch_ln_fwd(c.at<float>(ba.x1), params + bw.n2w, params + bw.n2b, c.at<bf16_t>(ba.xn2), nullptr,
                               c.at<float>(ba.mean2), c.at<float>(ba.rstd2), T, C, CP, nullptr, st));
-      {  // fc1 + GELU                                 :25-26
-        GemmParams g = {};
-        g.A = c.at<bf16_t>(ba.xn2); g.lda = CP; g.Wt = c.packed + bw.Wfc1; g.M = T; g.N = HP; g.K = CP;
-        g.bias = c.side + bw.bfc1; g.outb = c.at<bf16_t>(ba.u); g.outb2 = c.at<bf16_t>(ba.h); g.ldo = HP; g.flops = fl_mlp;
-        g.bytes = (double)T * (2.0 * C + 4.0 * p->HID) + 2.0 * C * p->HID;           // xn2 in; u, h out
-        RUN(srk_launch_gemm(LD_ROWS, EP_GELU, g, st));
-      }
-      {  // fc2 + residual                             :28, :277
-        GemmParams g = {};
+      {  // Mlp (:25-28) + second residual (:277): fc1 + GELU and fc2 + residual, as one kernel where it applies
+        GemmParams g1 = {};   // fc1 + GELU
+        g1.A = c.at<bf16_t>(ba.xn2); g1.lda = CP; g1.Wt = c.packed + bw.Wfc1; g1.M = T; g1.N = HP; g1.K = CP;
+        g1.bias = c.side + bw.bfc1; g1.outb = c.at<bf16_t>(ba.u); g1.outb2 = c.at<bf16_t>(ba.h); g1.ldo = HP; g1.flops = fl_mlp;
+        g1.bytes = (double)T * (2.0 * C + 4.0 * p->HID) + 2.0 * C * p->HID;           // xn2 in; u, h out
+        GemmParams g = {};    // fc2 + residual
         g.A = c.at<bf16_t>(ba.h); g.lda = HP; g.Wt = c.packed + bw.Wfc2; g.M = T; g.N = CP; g.K = HP;
         g.bias = c.side + bw.bfc2; g.res = c.at<float>(ba.x1); g.outf = c.at<float>(ba.x_out); g.ldo = CP;
         g.outb = (j == depth - 1) ? c.at<bf16_t>(w.layer_xb[l]) : nullptr;
@@ -771,7 +768,19 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
           g.xn_geom = make_wgeom(H, W, nb.shift);
           ln1_done = true;
         }
-        RUN(srk_launch_gemm(LD_ROWS, EP_RES, g, st));
+        GemmParams gf = g;    // fused: the hidden tile never leaves the CU between the two layers
+        gf.A = g1.A; gf.lda = CP; gf.Wt = g1.Wt; gf.K = CP; gf.bias = g1.bias; gf.W2 = g.Wt; gf.bias2 = g.bias; gf.HP = HP;
+        gf.u_out = w.training ? c.at<bf16_t>(ba.u) : nullptr;
+        gf.h_out = w.training ? c.at<bf16_t>(ba.h) : nullptr;
+        gf.flops = 2.0 * fl_mlp;
+        gf.bytes = (double)T * (2.0 * C + 4.0 * C + 4.0 * C + 2.0 * C + (w.training ? 4.0 * p->HID : 0.0)) + 4.0 * C * p->HID;   // xn2, x1 in; x2, xb | xn1 (, u, h) out
+        const int rc_mlp = srk_launch_mlp_fused(gf, st);
+        if (rc_mlp != SRK_NOT_COVERED) {
+          RUN(rc_mlp);
+        } else {
+          RUN(srk_launch_gemm(LD_ROWS, EP_GELU, g1, st));
+          RUN(srk_launch_gemm(LD_ROWS, EP_RES, g, st));
+        }
       }
     }
     {  // RSTB conv + residual                          :481-482
