@@ -93,12 +93,97 @@ def gen_g11():
     save("g11_ms_resunet", **arrays)
 
 
+HAT_TINY = dict(img_size=32, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=16, compress_ratio=3,
+                squeeze_factor=6, conv_scale=0.01, overlap_ratio=0.5, mlp_ratio=2.0, upscale=4, img_range=1.0, upsampler="pixelshuffle")
+
+
+def gen_g13():
+    """G13: HAT (hat_arch.py imports with the timm stand-in; einops is installed).  Index tables bit-exact (rpi_oca keeps its
+    negative entries), a tiny HAT end to end at three input sizes incl. a non-multiple of the window (reflect pad + crop +
+    dynamic mask), OCAB / HAB in isolation, and probes of the full HAT-SRx4 (BASELINE cfg4) forward."""
+    from oracle import hat_oracle as HO
+    ha = import_reference("hat_arch")
+    # index tables
+    arrays = {}
+    for ws in (8, 16):
+        cfg = HO.HATConfig(**{**HAT_TINY, "window_size": ws})
+        m = ha.HAT(**cfg.kwargs())
+        arrays[f"rpi_sa_ws{ws}"] = m.relative_position_index_SA.numpy()
+        arrays[f"rpi_oca_ws{ws}"] = m.relative_position_index_OCA.numpy()
+        arrays[f"mask_ws{ws}_48x32"] = (m.calculate_mask((48, 32)).numpy() != 0).astype(np.uint8)
+    save("g13_hat_index", **arrays)
+    # tiny end to end
+    cfg = HO.HATConfig(**HAT_TINY)
+    sd = HO.random_state_dict(cfg, seed=13, scale=2.0)
+    torch.manual_seed(0)
+    m = ha.HAT(**cfg.kwargs())
+    assert list(m.state_dict().keys()) == list(sd.keys()), "schema order drifted"
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    m.eval()
+    arrays = dict(weight_seed=np.array(13), weight_scale=np.array(2.0),
+                  weight_sha1=np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))))
+    for hw in ((32, 32), (32, 48), (20, 37)):
+        x = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(hw[0] * 100 + hw[1]))
+        with torch.no_grad():
+            y = m(x)
+        arrays[f"x_{hw[0]}x{hw[1]}"] = x.numpy()
+        arrays[f"y_{hw[0]}x{hw[1]}"] = y.numpy()
+    # one HAB (shifted) and the OCAB in isolation on a 32x48 token map
+    xt = torch.randn(1, 32 * 48, 24, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        params = {"attn_mask": m.calculate_mask((32, 48)), "rpi_sa": m.relative_position_index_SA, "rpi_oca": m.relative_position_index_OCA}
+        blk = m.layers[0].residual_group.blocks[1]
+        arrays["blk.x"] = xt.numpy()
+        arrays["blk.hab_shifted"] = blk(xt, (32, 48), params["rpi_sa"], params["attn_mask"]).numpy()
+        arrays["blk.hab_plain"] = m.layers[0].residual_group.blocks[0](xt, (32, 48), params["rpi_sa"], params["attn_mask"]).numpy()
+        arrays["blk.ocab"] = m.layers[1].residual_group.overlap_attn(xt, (32, 48), params["rpi_oca"]).numpy()
+        f = torch.randn(1, 24, 32, 32, generator=torch.Generator().manual_seed(6))
+        arrays["ff.x"] = f.numpy()
+        arrays["ff.y"] = m.forward_features(f).numpy()
+    # training-mode loss + gradients (drop_path 0): pins the oracle's autograd against the reference's
+    mt = ha.HAT(drop_path_rate=0.0, **cfg.kwargs())
+    mt.load_state_dict(sd, strict=True)
+    mt.train()
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(7))
+    t = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(8))
+    loss = torch.nn.functional.l1_loss(mt(x), t)
+    loss.backward()
+    arrays["train.x_seed"], arrays["train.target_seed"], arrays["train.loss"] = np.array(7), np.array(8), np.array(float(loss.detach()))
+    names = [n for n, _ in mt.named_parameters()]
+    arrays["train.grad_norms"] = np.array([float(p.grad.norm()) for _, p in mt.named_parameters()])
+    arrays["train.grad_names"] = np.array(names)
+    for n, p in mt.named_parameters():
+        if "layers.1.residual_group.overlap_attn" in n or "blocks.1.conv_block" in n or n.startswith(("conv_first", "conv_last")):
+            arrays["grad." + n] = p.grad.numpy().copy()
+    save("g13_hat_tiny", **arrays)
+    # full size probe
+    cfg = HO.HATConfig.sr_x4()
+    sd = HO.random_state_dict(cfg, seed=42, scale=1.0)
+    m = ha.HAT(**cfg.kwargs())
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    xin = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        yn = m(xin).numpy()
+    pg = np.random.RandomState(1).randint(0, yn.size, size=64)
+    n_params = sum(p.numel() for p in m.parameters())
+    save("g13_hat_cfg4_probe", probe_index=pg, probe_value=yn.reshape(-1)[pg], mean=np.array(yn.mean()), std=np.array(yn.std()),
+         sha1=np.array(sha1(yn)), shape=np.array(yn.shape), n_params=np.array(n_params), n_keys=np.array(len(m.state_dict())),
+         weight_seed=np.array(42), weight_scale=np.array(1.0), input_seed=np.array(0), batch=np.array(1))
+    print("G13 cfg4 params", n_params, "keys", len(m.state_dict()), "mean", yn.mean(), "std", yn.std(), "max", np.abs(yn).max())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if "--only-g11" in sys.argv:
         return gen_g11()
+    if "--only-g13" in sys.argv:
+        return gen_g13()
     gen_g11()
+    gen_g13()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------

@@ -200,3 +200,81 @@ def test_bf16_emulation_stays_within_bf16_noise_of_the_fp32_oracle():
         y = E.swinir_forward_emul(sd, cfg, torch.from_numpy(g["x_13x19"]))
     ref = torch.from_numpy(g["y_13x19"])
     assert y.shape == ref.shape and float((y - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+
+
+# ---- G13: HAT (reference modules/hat_arch.py; fixtures by oracle/make_golden.py::gen_g13) -----------------------------------
+HAT_TINY = dict(img_size=32, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=16, compress_ratio=3,
+                squeeze_factor=6, conv_scale=0.01, overlap_ratio=0.5, mlp_ratio=2.0, upscale=4, img_range=1.0, upsampler="pixelshuffle")
+
+
+def hat_tiny_weights():
+    from oracle import hat_oracle as HO
+    g = load_golden("g13_hat_tiny")
+    cfg = HO.HATConfig(**HAT_TINY)
+    sd = HO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g["weight_sha1"]), "HAT weight generator drifted from the one the fixtures were made with"
+    return g, cfg, sd
+
+
+def test_g13_hat_index_tables_bit_exact():
+    from oracle import hat_oracle as HO
+    g = load_golden("g13_hat_index")
+    for ws in (8, 16):
+        wse = ws + ws // 2
+        assert np.array_equal(HO.rpi_sa(ws), g[f"rpi_sa_ws{ws}"])
+        oca = HO.rpi_oca(ws, wse)
+        assert np.array_equal(oca, g[f"rpi_oca_ws{ws}"]) and oca.dtype == np.int64
+        assert oca.min() < 0                                    # the reference relies on negative-index wrap (hat_arch.py:911-918)
+        assert np.array_equal((O.shift_attn_mask(48, 32, ws, ws // 2) != 0).astype(np.uint8), g[f"mask_ws{ws}_48x32"])
+    assert int(HO.rpi_oca(16, 24).min()) == -880 and int(HO.rpi_oca(16, 24).max()) == 640
+
+
+def test_g13_hat_tiny_end_to_end_blocks_and_gradients():
+    from oracle import hat_oracle as HO
+    g, cfg, sd = hat_tiny_weights()
+    for hw in ((32, 32), (32, 48), (20, 37)):
+        x = torch.from_numpy(g[f"x_{hw[0]}x{hw[1]}"])
+        with torch.no_grad():
+            y = HO.hat_forward(sd, cfg, x)
+        ref = torch.from_numpy(g[f"y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape == (1, 3, hw[0] * 4, hw[1] * 4)
+        assert (y - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), hw
+    xt = torch.from_numpy(g["blk.x"])
+    with torch.no_grad():
+        p0, p1 = "layers.0.residual_group.blocks.0.", "layers.0.residual_group.blocks.1."
+        assert (HO.hab(xt, (32, 48), sd, p1, cfg, 2, 16, 8) - torch.from_numpy(g["blk.hab_shifted"])).abs().max() < 2e-5
+        assert (HO.hab(xt, (32, 48), sd, p0, cfg, 2, 16, 0) - torch.from_numpy(g["blk.hab_plain"])).abs().max() < 2e-5
+        assert (HO.ocab(xt, (32, 48), sd, "layers.1.residual_group.overlap_attn.", cfg, 2, 16) - torch.from_numpy(g["blk.ocab"])).abs().max() < 2e-5
+        assert (HO.forward_features(torch.from_numpy(g["ff.x"]), sd, cfg) - torch.from_numpy(g["ff.y"])).abs().max() < 2e-5
+    # autograd over the restatement against the reference's gradients
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(int(g["train.x_seed"])))
+    t = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(int(g["train.target_seed"])))
+    keys = HO.param_keys(cfg)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    loss = torch.nn.functional.l1_loss(HO.hat_forward({**sd, **leaves}, cfg, x), t)
+    grads = dict(zip(keys, torch.autograd.grad(loss, [leaves[k] for k in keys])))
+    assert abs(float(loss) - float(g["train.loss"])) < 1e-6
+    assert list(g["train.grad_names"]) == keys
+    for n, ref in zip(keys, g["train.grad_norms"]):
+        assert abs(float(grads[n].norm()) - float(ref)) <= 2e-4 * float(ref) + 1e-9, n
+    for k in g.files:
+        if k.startswith("grad."):
+            ref = torch.from_numpy(g[k])
+            assert (grads[k[5:]] - ref).abs().max() <= 1e-5 * max(1e-3, float(ref.abs().max())), k
+
+
+def test_g13_hat_cfg4_schema_and_probe():
+    """HAT-SRx4 (BASELINE cfg4): 20 772 507 parameters / 864 keys; one 64x64 forward against the reference's probes."""
+    from oracle import hat_oracle as HO
+    g = load_golden("g13_hat_cfg4_probe")
+    cfg = HO.HATConfig.sr_x4()
+    sd = HO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    assert len(sd) == int(g["n_keys"]) == 864
+    assert sum(sd[k].numel() for k in HO.param_keys(cfg)) == int(g["n_params"]) == 20772507
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    with torch.no_grad():
+        y = HO.hat_forward(sd, cfg, x).numpy()
+    assert tuple(y.shape) == tuple(g["shape"])
+    assert np.abs(y.reshape(-1)[g["probe_index"]] - g["probe_value"]).max() < 2e-5
+    assert abs(float(y.mean()) - float(g["mean"])) < 1e-5 and abs(float(y.std()) - float(g["std"])) < 1e-5
