@@ -164,6 +164,62 @@ int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float
                         const float* sumsq, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, const int32_t* nonfinite, srk_stream_t stream);
 
+/* ---- generic GEMM / 3x3 conv with the fused epilogues, for host-orchestrated models (HAT: tpu_superresolution_amd/hat_arch.py)
+ * D[m][n] = sum_k A[m][k] W[n][k] (+ epilogue).  A bf16: SRK_LD_ROWS [M][lda]; SRK_LD_CONV3 NHWC [B][H][Wd][CinP] (3x3, pad 1,
+ * K = 9 * CinP tap-major).  W bf16 [N][K].  N % 64 == 0 (N == 16 for the image head), K % 64 == 0. */
+enum { SRK_LD_ROWS = 0, SRK_LD_CONV3 = 1 };
+enum { SRK_EP_BF16 = 0,       /* outb = bf16(v + bias) */
+       SRK_EP_GELU = 3,       /* outb = bf16(u), outb2 = bf16(gelu(u)), u = v + bias */
+       SRK_EP_RES = 4,        /* outf = res + v + bias (fp32) [+ outb bf16 copy] [+ LayerNorm of the new row -> xn_out, N == 64/128/192] */
+       SRK_EP_LRELU = 6,      /* outb = bf16(leaky_relu(v + bias, scale)) */
+       SRK_EP_PS = 7,         /* conv + PixelShuffle(r): W rows permuted to (i*r + j)*Cs + c; store is the shuffled NHWC tensor */
+       SRK_EP_IMG = 8,        /* N == 16: outf NCHW image [B][Cimg][Hc][Wc] = v * inv_range + mean[c] (crop) */
+       SRK_EP_RES_BF16 = 10,  /* outb = bf16(res + v + bias) */
+       SRK_EP_MLP_FUSED = 100 /* (reserved; see srk_mlp_fused_fwd) */ };
+typedef struct {
+  int loader, epilogue;
+  const void* A; int lda;
+  const void* W;
+  int M, N, K;
+  int B, H, Wd, CinP;          /* conv geometry (M == B*H*Wd) */
+  int r, Cs;                   /* SRK_EP_PS */
+  const float* bias;
+  float* outf; void* outb; void* outb2;
+  const float* res; const void* aux;
+  int ldo;                     /* row stride (elements) of outf / outb / res */
+  float scale;                 /* SRK_EP_LRELU slope */
+  float inv_range; float mean[4]; int Cimg, Hc, Wc;     /* SRK_EP_IMG */
+  void* xn_out; float* xn_mean; float* xn_rstd; const float* xn_gamma; const float* xn_beta; int xn_C;   /* SRK_EP_RES fused LayerNorm */
+} srk_gemm_args;
+int srk_gemm_ex(const srk_gemm_args* args, srk_stream_t stream);
+/* Mlp.forward + residual (+ next LayerNorm) in one kernel (csrc/gemm_stream.hip): out = res + gelu(xn W1^T + b1) W2^T + b2.
+ * xn bf16 [M][192], W1 bf16 [384][192], W2 bf16 [192][384], res / out fp32 [M][192]; C 180 / hidden 360 zero-padded. */
+int srk_mlp_fused_fwd(const uint16_t* xn, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* res,
+                      float* out, uint16_t* out_bf16, uint16_t* xn_next, float* xn_mean, float* xn_rstd, const float* xn_gamma,
+                      const float* xn_beta, int xn_C, int M, srk_stream_t stream);
+/* image -> padded, normalised NHWC4 (check_image_size + (x - mean) * range, hat_arch.py:963-975) and conv_first (fp32 VALU) */
+int srk_img_prep(const float* x, float* out, int B, int Cimg, int H0, int W0, int H, int W, float range, const float* mean3, srk_stream_t stream);
+int srk_stem_conv(const float* img4, const float* weight, const float* bias, float* out, int B, int H, int W, int Cin, int C, int CP,
+                  srk_stream_t stream);
+
+/* ---- HAT (reference hat_arch.py) ------------------------------------------------------------------------------------------------
+ * Window attention with 256 queries per window, forward.  qkv bf16 [T][ldq] in RASTER token order straight from the qkv linear
+ * (q | k | v at columns 0 / CA / 2 CA, head h at +32 h, head_dim zero-padded to 32, q NOT pre-scaled); bias fp32 dense
+ * [num_heads][256][NK]; out bf16 [T][ldo] raster.  overlap == 0: (shifted) window self-attention, wh x ww windows with
+ * wh * ww == 256 (WindowAttention.forward :163-197 + the roll / partition / reverse of HAB.forward :298-319; the shift mask of
+ * calculate_mask :921-941 is evaluated arithmetically).  overlap == 8: overlapping cross-attention of OCAB.forward :403-432
+ * (16 x 16 queries, 24 x 24 zero-padded keys, NK = 576). */
+int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* bias, uint16_t* out, int ldo, int B, int H, int W, int wh,
+                             int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap, srk_stream_t stream);
+/* ChannelAttention gate of CAB (:41-57): gate[b][c] = out_scale * sigmoid(W2 relu(W1 mean_b + b1) + b2), mean over the HW tokens
+ * of x bf16 [B*HW][CP]; w1 [S][C], w2 [C][S] fp32 (the 1x1 convs).  workspace: srk_channel_gate_workspace bytes. */
+size_t srk_channel_gate_workspace(int B, int HW, int CP);
+int srk_channel_gate(const uint16_t* x, void* workspace, const float* w1, const float* b1, const float* w2, const float* b2, float out_scale,
+                     float* gate, int B, int HW, int C, int CP, int S, srk_stream_t stream);
+/* HAB.forward :322-323: x += conv * gate[sample] in place (fp32 [rows][CP]) and, if xn != null, xn = bf16(LayerNorm(x)) */
+int srk_cab_add_ln(float* x, const uint16_t* conv, const float* gate, const float* gamma, const float* beta, uint16_t* xn, int64_t rows,
+                   int rows_per_sample, int C, int CP, srk_stream_t stream);
+
 /* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
 enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1,          /* classical SR           (network_swinir.py:740-745, :813-817) */
        SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2,    /* lightweight SR         (:746-749, :818-822) */

@@ -1,0 +1,158 @@
+"""HAT on the HIP path (BASELINE cfg4): the 256-query window attention kernels against a plain torch fp32
+reference of the same op, the CAB helper kernels, and the whole model against the reference's golden vectors (G13) and the
+CPU oracle (oracle/hat_oracle.py, pinned by tests/test_oracle_golden.py::test_g13_*).
+
+Tolerances as for SwinIR (tests/test_gpu_model.py): bf16 MFMA operands with fp32 accumulation / softmax / LayerNorm /
+residual stream -> forward max|err| <= 1.2e-2 * max|ref|; attention kernels alone (bf16 in, bf16 out) 2e-2 * max|ref|."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import hat_oracle as HO
+from oracle import swinir_oracle as O
+from test_oracle_golden import hat_tiny_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from tpu_superresolution_amd._lib import check, lib
+    return check, lib()
+
+
+def _attn_reference(qkv, bias, B, H, W, ws, shift, nH, scale, overlap):
+    """fp32 torch restatement on the bf16-rounded inputs: q/k/v [B, H*W, nH, 32] from the raster qkv tensor."""
+    CA = nH * 32
+    t = qkv.float().reshape(B, H * W, 3, nH, 32)
+    q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+    qi = torch.from_numpy(O.window_token_index(H, W, ws, shift))                      # [nW, 256]
+    nW = qi.shape[0]
+    qw = q[:, qi.reshape(-1)].reshape(B, nW, ws * ws, nH, 32).permute(0, 1, 3, 2, 4)
+    if overlap:
+        ki_np, valid_np = HO.overlap_window_index(H, W, ws, ws + overlap)
+        ki, valid = torch.from_numpy(ki_np), torch.from_numpy(valid_np)
+        kw = (k[:, ki.reshape(-1)].reshape(B, nW, -1, nH, 32) * valid[None, :, :, None, None]).permute(0, 1, 3, 2, 4)
+        vw = (v[:, ki.reshape(-1)].reshape(B, nW, -1, nH, 32) * valid[None, :, :, None, None]).permute(0, 1, 3, 2, 4)
+    else:
+        kw = k[:, qi.reshape(-1)].reshape(B, nW, ws * ws, nH, 32).permute(0, 1, 3, 2, 4)
+        vw = v[:, qi.reshape(-1)].reshape(B, nW, ws * ws, nH, 32).permute(0, 1, 3, 2, 4)
+    s = (qw @ kw.transpose(-2, -1)) * scale + bias[None, None]
+    if shift and not overlap:
+        s = s + torch.from_numpy(O.shift_attn_mask(H, W, ws, shift))[None, :, None]
+    out = (s.softmax(-1) @ vw).permute(0, 1, 3, 2, 4).reshape(B, nW * ws * ws, CA)      # window order
+    res = torch.zeros(B, H * W, CA)
+    res[:, qi.reshape(-1)] = out
+    return res.reshape(B * H * W, CA)
+
+
+@pytest.mark.parametrize("shift,overlap,H,W", [(0, 0, 32, 48), (8, 0, 32, 48), (8, 0, 64, 32), (0, 8, 32, 48), (0, 8, 16, 16)])
+def test_win256_attention_forward_vs_torch(shift, overlap, H, W):
+    check, L = _lib()
+    B, nH, ws = 2, 3, 16
+    CA = nH * 32
+    g = torch.Generator().manual_seed(H * 7 + W + shift + overlap)
+    qkv = (torch.randn(B * H * W, 3 * CA, generator=g) * 0.8).to(torch.bfloat16)
+    qkv.view(B * H * W, 3, nH, 32)[..., 30:] = 0                                          # head_dim 30 zero-padded to 32
+    NK = (ws + overlap) ** 2 if overlap else ws * ws
+    bias = torch.randn(nH, 256, NK, generator=g) * 0.5
+    scale = 30 ** -0.5
+    ref = _attn_reference(qkv, bias, B, H, W, ws, shift, nH, scale, overlap)
+    out = torch.empty(B * H * W, CA, dtype=torch.bfloat16, device="cuda")
+    q_d, b_d = qkv.cuda(), bias.cuda()
+    check(L.srk_win256_attention_fwd(q_d.data_ptr(), 3 * CA, CA, b_d.data_ptr(), out.data_ptr(), CA, B, H, W, ws, ws, shift, shift, nH,
+                                     scale, overlap, torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().float()
+    err = float((got - ref).abs().max())
+    assert err <= 2e-2 * float(ref.abs().max()), f"max err {err:.3e} vs max|ref| {float(ref.abs().max()):.3e}"
+    assert float((got.view(-1, nH, 32)[..., 30:]).abs().max()) == 0.0                      # pad channels stay zero
+
+
+def test_channel_gate_and_cab_add_ln_vs_torch():
+    check, L = _lib()
+    B, HW, C, CP, S = 3, 700, 180, 192, 6
+    g = torch.Generator().manual_seed(1)
+    conv = torch.zeros(B * HW, CP)
+    conv[:, :C] = torch.randn(B * HW, C, generator=g)
+    conv = conv.to(torch.bfloat16)
+    w1, b1, w2, b2 = torch.randn(S, C, generator=g) * 0.3, torch.randn(S, generator=g), torch.randn(C, S, generator=g), torch.randn(C, generator=g)
+    mean = conv.float().reshape(B, HW, CP)[:, :, :C].mean(1)
+    gate_ref = 0.01 * torch.sigmoid(torch.relu(mean @ w1.t() + b1) @ w2.t() + b2)
+    ws_ = torch.empty(int(L.srk_channel_gate_workspace(B, HW, CP)), dtype=torch.uint8, device="cuda")
+    gate = torch.empty(B, CP, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dev = [t.cuda() for t in (conv, w1, b1, w2, b2)]
+    check(L.srk_channel_gate(dev[0].data_ptr(), ws_.data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), 0.01,
+                             gate.data_ptr(), B, HW, C, CP, S, st))
+    assert float((gate.cpu()[:, :C] - gate_ref).abs().max()) <= 1e-6 and float(gate.cpu()[:, C:].abs().max()) == 0.0
+    x = torch.zeros(B * HW, CP)
+    x[:, :C] = torch.randn(B * HW, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    want = x[:, :C] + conv.float()[:, :C] * gate_ref.repeat_interleave(HW, 0)
+    want_n = torch.nn.functional.layer_norm(want, (C,), gamma, beta, 1e-5)
+    xd, xn = x.cuda(), torch.empty(B * HW, CP, dtype=torch.bfloat16, device="cuda")
+    check(L.srk_cab_add_ln(xd.data_ptr(), dev[0].data_ptr(), gate.data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(), xn.data_ptr(),
+                           B * HW, HW, C, CP, st))
+    assert float((xd.cpu()[:, :C] - want).abs().max()) <= 1e-5 and float(xd.cpu()[:, C:].abs().max()) == 0.0
+    assert float((xn.cpu().float()[:, :C] - want_n).abs().max()) <= 2e-2
+
+
+def _build(cfg, sd):
+    import tpu_superresolution_amd as T
+    m = T.HAT(**cfg.kwargs())
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    return m.cuda().eval()
+
+
+def test_hat_tiny_forward_vs_reference_golden():
+    g, cfg, sd = hat_tiny_weights()
+    m = _build(cfg, sd)
+    for hw in ((32, 32), (32, 48), (20, 37)):         # exact multiple / non-square / reflect-pad + crop + dynamic mask
+        x = torch.from_numpy(g[f"x_{hw[0]}x{hw[1]}"])
+        with torch.no_grad():
+            y = m(x.cuda()).cpu()
+        ref = torch.from_numpy(g[f"y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape and y.dtype == torch.float32
+        err = float((y - ref).abs().max())
+        print(f"HAT tiny {hw}: max err {err:.3e} ({err / float(ref.abs().max()):.2e} of range)")
+        assert err <= 1.2e-2 * float(ref.abs().max()), f"{hw}: max err {err:.3e} vs ref max {float(ref.abs().max()):.3e}"
+    out_sd = m.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(out_sd[k].cpu(), v), k
+
+
+def test_hat_cfg4_forward_probes_and_batch():
+    """HAT-SRx4 (BASELINE cfg4: window 16, dim 180, 6x6 blocks): one image against the reference's probes, then the cfg4 batch
+    (bs 16) against the single-image run (no cross-sample operator: the ChannelAttention pool is per sample)."""
+    g = load_golden("g13_hat_cfg4_probe")
+    cfg = HO.HATConfig.sr_x4()
+    sd = HO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    m = _build(cfg, sd)
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) and len(m.state_dict()) == int(g["n_keys"])
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+    assert tuple(y.shape) == tuple(g["shape"])
+    err = np.abs(y.numpy().reshape(-1)[g["probe_index"]] - g["probe_value"]).max()
+    print(f"HAT cfg4: probe max err {err:.3e}, mean {float(y.mean()):.5f} (ref {float(g['mean']):.5f})")
+    assert err <= 5e-3 and abs(float(y.mean()) - float(g["mean"])) <= 2e-3      # default-scale weights: output in the image range
+    xb = torch.rand(16, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    xb[5] = x[0]
+    with torch.no_grad():
+        yb = m(xb.cuda()).cpu()
+    assert yb.shape == (16, 3, 256, 256) and torch.isfinite(yb).all()
+    assert float((yb[5] - y[0]).abs().max()) <= 4e-3 * float(y.abs().max())     # different M -> different GEMM kernels / summation order
+
+
+def test_hat_errors_are_loud():
+    import tpu_superresolution_amd as T
+    cfg = HO.HATConfig(**{**HO.HATConfig.sr_x4().__dict__, "depths": (1,), "num_heads": (6,)})
+    m = T.HAT(**cfg.kwargs())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 32, 32))
+    with pytest.raises(NotImplementedError, match="window_size=8"):
+        T.HAT(**{**cfg.kwargs(), "window_size": 8}).cuda().eval()(torch.rand(1, 3, 32, 32, device="cuda"))
+    with pytest.raises(NotImplementedError, match="training is not built"):
+        m.cuda().train()(torch.rand(1, 3, 32, 32, device="cuda"))

@@ -35,6 +35,20 @@ class SwinIRConfig(C.Structure):
                 ("mean", C.c_float * 3), ("qk_scale", C.c_float), ("resi_connection", C.c_int)]
 
 
+class GemmArgs(C.Structure):
+    """srk_gemm_args (include/srk.h)."""
+    _fields_ = [("loader", C.c_int), ("epilogue", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("CinP", C.c_int),
+                ("r", C.c_int), ("Cs", C.c_int), ("bias", C.c_void_p), ("outf", C.c_void_p), ("outb", C.c_void_p),
+                ("outb2", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("ldo", C.c_int), ("scale", C.c_float),
+                ("inv_range", C.c_float), ("mean", C.c_float * 4), ("Cimg", C.c_int), ("Hc", C.c_int), ("Wc", C.c_int),
+                ("xn_out", C.c_void_p), ("xn_mean", C.c_void_p), ("xn_rstd", C.c_void_p), ("xn_gamma", C.c_void_p),
+                ("xn_beta", C.c_void_p), ("xn_C", C.c_int)]
+
+
+LD_ROWS, LD_CONV3 = 0, 1
+EP_BF16, EP_GELU, EP_RES, EP_LRELU, EP_PS, EP_IMG, EP_RES_BF16 = 0, 3, 4, 6, 7, 8, 10
+
 UPSAMPLER_PIXELSHUFFLE = 1
 UPSAMPLER_PIXELSHUFFLEDIRECT = 2
 UPSAMPLER_NEAREST_CONV = 3
@@ -77,6 +91,14 @@ _SIGNATURES = {
     "srk_batch_psnr": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
     "srk_grad_sumsq": (_i, [_vp, _i64, _vp, _vp]),
     "srk_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+    "srk_gemm_ex": (_i, [C.POINTER(GemmArgs), _vp]),
+    "srk_mlp_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "srk_img_prep": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, C.POINTER(C.c_float * 3), _vp]),
+    "srk_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_win256_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "srk_channel_gate_workspace": (_sz, [_i, _i, _i]),
+    "srk_channel_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_cab_add_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_swinir_plan_create": (_i, [C.POINTER(SwinIRConfig), C.POINTER(_vp)]),
     "srk_swinir_plan_destroy": (None, [_vp]),
     "srk_swinir_param_floats": (_i64, [_vp]),
