@@ -4,6 +4,7 @@
     python bench.py --gpus N --steps K --warmup W                 (N > 1 without WORLD_SIZE: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --config cfg2                                 (SwinIR-light x2 inference, 48x48 LR, bs 16: BASELINE cfg2)
+    python bench.py --config cfg4                                 (HAT x4 inference, 64x64 LR, bs 16: BASELINE cfg4)
 
 A step = forward + L1 loss + backward + (N>1: RCCL gradient all-reduce, overlapped) + clip 1.0 + AdamW on
 one batch of synthetic LR/HR patches already resident in HBM.  Prints ONE JSON line on rank 0.
@@ -132,22 +133,45 @@ COMPULSORY_TRAIN_FACTOR = 3.25
 OPTIMIZER_BYTES_PER_STEP = 11_900_199 * 28
 
 
-def bench_cfg2(args):
-    """BASELINE cfg2: SwinIR-light x2 (dim 60, 4x6 blocks, window 8, pixelshuffledirect) inference, 48x48 LR, bs 16.
-    A step = one forward of one batch resident in HBM.  Replicas only for N > 1 (no collective)."""
-    import torch.distributed as dist
+INFER = {
+    "cfg2": dict(metric="HR pixels/sec, SwinIR-light x2 inference, 48x48 LR, bs=16/GPU", batch=16, lr=48, scale=2, flop_per_image=4.818e9,
+                 workload="BASELINE cfg2: SwinIR-light x2 (dim 60, 4x6 blocks, window 8, pixelshuffledirect) inference forward, 48x48 LR -> "
+                          "96x96 HR, random-init weights",
+                 kernel="linear-layer GEMMs of the light model (gemm_kernel / gemm_stream*, csrc/gemm*.hip)"),
+    "cfg4": dict(metric="HR pixels/sec, HAT x4 inference, 64x64 LR, bs=16/GPU", batch=16, lr=64, scale=4, flop_per_image=207.76e9,
+                 workload="BASELINE cfg4: HAT-SRx4 (dim 180, 6x6 HAB + 6 OCAB, window 16, overlap 0.5, CAB) inference forward, 64x64 LR -> "
+                          "256x256 HR, random-init weights",
+                 kernel="linear-layer GEMMs (persistent LDS-DMA GEMMs + fused MLP kernel, csrc/gemm_stream.hip)"),
+}
+
+
+def build_infer_model(name, device):
     import tpu_superresolution_amd as T
+    torch.manual_seed(42)
+    if name == "cfg2":
+        m = T.SwinIR(upscale=2, in_chans=3, img_size=64, window_size=8, img_range=1.0, depths=[6] * 4, embed_dim=60,
+                     num_heads=[6] * 4, mlp_ratio=2, upsampler="pixelshuffledirect")
+    else:       # official HAT-SRx4 hyper-parameters (the reference repo never instantiates HAT: SURVEY 0)
+        m = T.HAT(upscale=4, in_chans=3, img_size=64, window_size=16, compress_ratio=3, squeeze_factor=30, conv_scale=0.01,
+                  overlap_ratio=0.5, img_range=1.0, depths=[6] * 6, embed_dim=180, num_heads=[6] * 6, mlp_ratio=2,
+                  upsampler="pixelshuffle", resi_connection="1conv")
+    return m.to(device).eval()
+
+
+def bench_inference(args):
+    """BASELINE cfg2 / cfg4: a step = one forward of one batch resident in HBM.  Replicas only for N > 1 (no collective)."""
+    import torch.distributed as dist
     from tpu_superresolution_amd import _lib
     from tpu_superresolution_amd.distributed import init_from_env
+    spec = INFER[args.config]
     rank, world, local = init_from_env("nccl") if args.gpus > 1 else (0, 1, 0)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    torch.manual_seed(42)
-    model = T.SwinIR(upscale=2, in_chans=3, img_size=64, window_size=8, img_range=1.0, depths=[6] * 4, embed_dim=60,
-                     num_heads=[6] * 4, mlp_ratio=2, upsampler="pixelshuffledirect").to(device).eval()
-    bs = args.batch or 16
-    x = torch.rand(bs, 3, 48, 48, generator=torch.Generator().manual_seed(rank)).to(device)
-    flop_per_image = 4.818e9                    # SURVEY 6 / 8d (FlopCounterMode on the reference)
+    model = build_infer_model(args.config, device)
+    bs = args.batch or spec["batch"]
+    x = torch.rand(bs, 3, spec["lr"], spec["lr"], generator=torch.Generator().manual_seed(rank)).to(device)
+    flop_per_image = spec["flop_per_image"]                    # SURVEY 6 / 8d (FlopCounterMode on the reference)
+    hr_px = bs * (spec["lr"] * spec["scale"]) ** 2
     lib = _lib.lib()
 
     def barrier():
@@ -160,7 +184,7 @@ def bench_cfg2(args):
             y = model(x)
         graph = None
         if not args.no_graph:
-            # ~150 small launches per forward: replay them as one hipGraph (the eager loop is launch-bound)
+            # a few hundred launches per forward: replay them as one hipGraph
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -190,12 +214,14 @@ def bench_cfg2(args):
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
             _lib.check(lib.srk_probe_end(C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
             if n.value:
-                gbs, tfl = by.value / (ms.value * 1e-3) / 1e9, fl.value / (ms.value * 1e-3) / 1e12
-                roof = {"bound": "hbm", "kernel": "linear-layer GEMMs of the light model (gemm_kernel / gemm_stream*, csrc/gemm*.hip)",
-                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                        "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value,
-                        "avg_launch_us": 1e3 * ms.value / n.value,
-                        "mfma": {"achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS}}
+                tfl = fl.value / (ms.value * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": spec["kernel"], "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tfl / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launches": n.value, "avg_launch_us": 1e3 * ms.value / n.value,
+                        "share_of_step": (ms.value / 5) / (1e3 * elapsed / args.steps)}
+                if by.value > 0:
+                    gbs = by.value / (ms.value * 1e-3) / 1e9
+                    roof["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_launch": by.value / n.value}
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,45 +230,51 @@ def bench_cfg2(args):
         raise SystemExit("non-finite output during the benchmark")
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * bs * 96 * 96 * args.steps / elapsed
+        value = world * hr_px * args.steps / elapsed
         tfl_step = bs * flop_per_image / (ms_per_step * 1e-3) / 1e12
-        out = {"metric": "HR pixels/sec, SwinIR-light x2 inference, 48x48 LR, bs=16/GPU", "value": value, "unit": "HR pixels/s",
+        out = {"metric": spec["metric"], "value": value, "unit": "HR pixels/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE cfg2: SwinIR-light x2 (dim 60, 4x6 blocks, window 8, pixelshuffledirect) inference "
-                                      "forward, 48x48 LR -> 96x96 HR, random-init weights", "batch_per_gpu": bs,
-                          "global_batch": bs * world, "parallelism": f"replicas{world}", "hip_graph": graph is not None,
-                          "per_gpu_value": value / world, "step_tflops_per_gpu": tfl_step}}
+               "config": {"workload": spec["workload"], "batch_per_gpu": bs, "global_batch": bs * world, "parallelism": f"replicas{world}",
+                          "hip_graph": graph is not None, "per_gpu_value": value / world, "step_tflops_per_gpu": tfl_step}}
         if roof is not None:
             roof["step"] = {"mfma_frac": tfl_step / MFMA_BF16_PEAK_TFLOPS, "algorithmic_tflop_per_step": bs * flop_per_image / 1e12}
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_cfg2()
+            out["cpu_baseline"] = cpu_baseline_infer(args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline_cfg2(steps=3, batch=16):
-    from oracle import swinir_oracle as O
+def cpu_baseline_infer(name, steps=3):
+    spec = INFER[name]
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     threads = int(os.environ.get("SRK_CPU_BASELINE_THREADS", max(1, min(avail, 32))))
     torch.set_num_threads(threads)
-    cfg = O.SwinIRConfig.light_x2()
-    sd = O.random_state_dict(cfg, 42, 1.0)
-    x = torch.rand(batch, 3, 48, 48, generator=torch.Generator().manual_seed(0))
+    if name == "cfg2":
+        from oracle import swinir_oracle as O
+        cfg, batch = O.SwinIRConfig.light_x2(), 16
+        sd = O.random_state_dict(cfg, 42, 1.0)
+        fwd = lambda t: O.swinir_forward(sd, cfg, t)
+    else:
+        from oracle import hat_oracle as HO
+        cfg, batch = HO.HATConfig.sr_x4(), 2
+        sd = HO.random_state_dict(cfg, 42, 1.0)
+        fwd = lambda t: HO.hat_forward(sd, cfg, t)
+    x = torch.rand(batch, 3, spec["lr"], spec["lr"], generator=torch.Generator().manual_seed(0))
     times = []
     with torch.no_grad():
-        O.swinir_forward(sd, cfg, x)
+        fwd(x)
         for _ in range(steps):
             t0 = time.perf_counter()
-            O.swinir_forward(sd, cfg, x)
+            fwd(x)
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": batch * 96 * 96 / med, "unit": "HR pixels/s", "cores": threads, "kind": "port",
+    return {"value": batch * (spec["lr"] * spec["scale"]) ** 2 / med, "unit": "HR pixels/s", "cores": threads, "kind": "port",
             "sample": f"{steps} fp32 forwards of the CPU oracle at batch {batch} (median {med:.2f} s), same model"}
 
 
@@ -251,21 +283,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["cfg3", "cfg2"], default="cfg3",
-                    help="cfg3 (default): the headline train step; cfg2: SwinIR-light x2 inference")
+    ap.add_argument("--config", choices=["cfg3", "cfg2", "cfg4"], default="cfg3",
+                    help="cfg3 (default): the headline train step; cfg2: SwinIR-light x2 inference; cfg4: HAT x4 inference")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (BASELINE: 32 for cfg3, 16 for cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.config == "cfg3" else 200
+        args.steps = {"cfg3": 20, "cfg2": 200, "cfg4": 10}[args.config]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])           # never returns
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.config == "cfg2":
-        return bench_cfg2(args)
+    if args.config in INFER:
+        return bench_inference(args)
     args.batch = args.batch or 32
     import torch.distributed as dist
     import tpu_superresolution_amd as T

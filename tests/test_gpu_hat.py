@@ -91,7 +91,8 @@ def test_channel_gate_and_cab_add_ln_vs_torch():
     want = x[:, :C] + conv.float()[:, :C] * gate_ref.repeat_interleave(HW, 0)
     want_n = torch.nn.functional.layer_norm(want, (C,), gamma, beta, 1e-5)
     xd, xn = x.cuda(), torch.empty(B * HW, CP, dtype=torch.bfloat16, device="cuda")
-    check(L.srk_cab_add_ln(xd.data_ptr(), dev[0].data_ptr(), gate.data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(), xn.data_ptr(),
+    gd, bd = gamma.cuda(), beta.cuda()          # keep the device copies alive across the call
+    check(L.srk_cab_add_ln(xd.data_ptr(), dev[0].data_ptr(), gate.data_ptr(), gd.data_ptr(), bd.data_ptr(), xn.data_ptr(),
                            B * HW, HW, C, CP, st))
     assert float((xd.cpu()[:, :C] - want).abs().max()) <= 1e-5 and float(xd.cpu()[:, C:].abs().max()) == 0.0
     assert float((xn.cpu().float()[:, :C] - want_n).abs().max()) <= 2e-2
