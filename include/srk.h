@@ -204,13 +204,15 @@ int srk_stem_conv(const float* img4, const float* weight, const float* bias, flo
 
 /* ---- HAT (reference hat_arch.py) ------------------------------------------------------------------------------------------------
  * Window attention with 256 queries per window, forward.  qkv bf16 [T][ldq] in RASTER token order straight from the qkv linear
- * (q | k | v at columns 0 / CA / 2 CA, head h at +32 h, head_dim zero-padded to 32, q NOT pre-scaled); bias fp32 dense
- * [num_heads][256][NK]; out bf16 [T][ldo] raster.  overlap == 0: (shifted) window self-attention, wh x ww windows with
+ * (q | k | v at columns 0 / CA / 2 CA, head h at +32 h, head_dim zero-padded to 32, q NOT pre-scaled); out bf16 [T][ldo] raster.
+ * bias: table_rows == 0: dense fp32 [num_heads][256][NK]; table_rows > 0 (16 x 16 windows): the relative_position_bias_table
+ * parameter itself, fp32 [table_rows][num_heads] (961 rows, 1521 for the overlapping form) -- the kernel stages the head's
+ * column in LDS and evaluates relative_position_index_SA / _OCA (:881-918) in closed form, negative OCA indices wrapped.  overlap == 0: (shifted) window self-attention, wh x ww windows with
  * wh * ww == 256 (WindowAttention.forward :163-197 + the roll / partition / reverse of HAB.forward :298-319; the shift mask of
  * calculate_mask :921-941 is evaluated arithmetically).  overlap == 8: overlapping cross-attention of OCAB.forward :403-432
  * (16 x 16 queries, 24 x 24 zero-padded keys, NK = 576). */
-int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* bias, uint16_t* out, int ldo, int B, int H, int W, int wh,
-                             int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap, srk_stream_t stream);
+int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* bias, int table_rows, uint16_t* out, int ldo, int B, int H,
+                             int W, int wh, int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap, srk_stream_t stream);
 /* ChannelAttention gate of CAB (:41-57): gate[b][c] = out_scale * sigmoid(W2 relu(W1 mean_b + b1) + b2), mean over the HW tokens
  * of x bf16 [B*HW][CP]; w1 [S][C], w2 [C][S] fp32 (the 1x1 convs).  workspace: srk_channel_gate_workspace bytes. */
 size_t srk_channel_gate_workspace(int B, int HW, int CP);

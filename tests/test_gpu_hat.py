@@ -60,12 +60,23 @@ def test_win256_attention_forward_vs_torch(shift, overlap, H, W):
     ref = _attn_reference(qkv, bias, B, H, W, ws, shift, nH, scale, overlap)
     out = torch.empty(B * H * W, CA, dtype=torch.bfloat16, device="cuda")
     q_d, b_d = qkv.cuda(), bias.cuda()
-    check(L.srk_win256_attention_fwd(q_d.data_ptr(), 3 * CA, CA, b_d.data_ptr(), out.data_ptr(), CA, B, H, W, ws, ws, shift, shift, nH,
+    check(L.srk_win256_attention_fwd(q_d.data_ptr(), 3 * CA, CA, b_d.data_ptr(), 0, out.data_ptr(), CA, B, H, W, ws, ws, shift, shift, nH,
                                      scale, overlap, torch.cuda.current_stream().cuda_stream))
     got = out.cpu().float()
     err = float((got - ref).abs().max())
     assert err <= 2e-2 * float(ref.abs().max()), f"max err {err:.3e} vs max|ref| {float(ref.abs().max()):.3e}"
     assert float((got.view(-1, nH, 32)[..., 30:]).abs().max()) == 0.0                      # pad channels stay zero
+    # table mode: the kernel indexes the bias table itself through the closed-form relative position index -- must give exactly
+    # what the dense expansion of the same table (oracle: negative rpi_oca wrapped) gives
+    rows = (2 * ws + overlap - 1) ** 2
+    table = torch.randn(rows, nH, generator=g) * 0.5
+    dense = HO.oca_bias(table, ws, ws + overlap) if overlap else HO.sa_bias(table, ws)
+    t_d, d_d = table.cuda(), dense.cuda()
+    out_t, out_d = torch.empty_like(out), torch.empty_like(out)
+    for src, n_rows, dst in ((t_d, rows, out_t), (d_d, 0, out_d)):
+        check(L.srk_win256_attention_fwd(q_d.data_ptr(), 3 * CA, CA, src.data_ptr(), n_rows, dst.data_ptr(), CA, B, H, W, ws, ws, shift, shift,
+                                         nH, scale, overlap, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(out_t, out_d)
 
 
 def test_channel_gate_and_cab_add_ln_vs_torch():

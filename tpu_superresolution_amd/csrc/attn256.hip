@@ -29,7 +29,8 @@ constexpr int KP = 40;      // LDS row pitch (elements) of the K / V tiles
 struct Win256Params {
   const bf16_t* qkv;   // [T][ldq]
   bf16_t* out;         // [T][ldo]
-  const float* bias;   // [nH][256][NK]
+  const float* bias;   // dense: [nH][256][NK];  table: the relative_position_bias_table parameter [table_rows][nH]
+  int table_rows;      // > 0: bias comes from the table through the closed-form relative position index (no dense tensor)
   int ldq, ldo, CA;
   int B, H, W;         // feature map
   int wh, ww;          // query window (wh * ww == 256)
@@ -41,12 +42,18 @@ struct Win256Params {
 
 __device__ __forceinline__ int region_label(int v, int n, int w, int s) { return v < n - w ? 0 : (v < n - s ? 1 : 2); }
 
-template <int NT, bool OCA>        // NT = key tiles of 16 (16: 256 keys, 36: 576 keys)
+// TABLE: the bias of a (query, key) pair is looked up in the head's column of the bias table, staged once in LDS (3.8 KB / 6 KB),
+// through the closed-form index -- rpi_sa[p][k] = (yp - yk + ws - 1)(2 ws - 1) + (xp - xk + ws - 1) (hat_arch.py:881-894),
+// rpi_oca[p][k] = (yk - yp + ws - wse + 1)(ws + wse - 1) + (xk - xp + ws - wse + 1), wrapped by the table length when negative
+// (:896-918 + torch's negative indexing) -- instead of streaming a dense [256][NK] fp32 slab per workgroup from L2.
+template <int NT, bool OCA, bool TABLE>        // NT = key tiles of 16 (16: 256 keys, 36: 576 keys)
 __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params p) {
   constexpr int NK = NT * 16;
+  constexpr int KW = OCA ? 24 : 16;                      // key-window width in table mode (16 x 16 / 24 x 24 windows)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);          // [NK][KP]
   bf16_t* Vs = Ks + NK * KP;                             // [NK][KP]
+  float* tab = reinterpret_cast<float*>(Vs + NK * KP);   // [table_rows] (TABLE)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.x % p.nH;
@@ -89,6 +96,9 @@ __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params
       *reinterpret_cast<uint4*>(Vs + kk * KP + 8 * c) = vv[c];
     }
   }
+  if constexpr (TABLE) {
+    for (int i = tid; i < p.table_rows; i += 256) tab[i] = p.bias[(long long)i * p.nH + h];
+  }
   __syncthreads();
 
   const float* bias_h = p.bias + (long long)h * 256 * NK;
@@ -118,7 +128,26 @@ __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params
     float mx = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const float4 bv = *reinterpret_cast<const float4*>(brow + 16 * j);
+      float4 bv;
+      if constexpr (TABLE) {
+        float be[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kl = 16 * j + 4 * g + e;
+          const int ky = kl / KW, kx = kl - ky * KW;
+          int idx;
+          if constexpr (OCA) {
+            idx = (ky - qy - 7) * 39 + (kx - qx - 7);                 // ws 16, wse 24: off = -7, 16 + 24 - 1 = 39
+            if (idx < 0) idx += p.table_rows;
+          } else {
+            idx = (qy - ky + 15) * 31 + (qx - kx + 15);
+          }
+          be[e] = tab[idx];
+        }
+        bv = make_float4(be[0], be[1], be[2], be[3]);
+      } else {
+        bv = *reinterpret_cast<const float4*>(brow + 16 * j);
+      }
       float v0 = s[j][0] * p.scale + bv.x, v1 = s[j][1] * p.scale + bv.y, v2 = s[j][2] * p.scale + bv.z, v3 = s[j][3] * p.scale + bv.w;
       if (masked) {
         float vv[4] = {v0, v1, v2, v3};
@@ -173,12 +202,12 @@ __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params
   }
 }
 
-template <int NT, bool OCA>
+template <int NT, bool OCA, bool TABLE>
 int launch(const Win256Params& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)2 * NT * 16 * KP * sizeof(bf16_t);
+  constexpr size_t lds = (size_t)2 * NT * 16 * KP * sizeof(bf16_t) + (TABLE ? 1536 * sizeof(float) : 0);
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_fwd_kernel<NT, OCA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_fwd_kernel<NT, OCA, TABLE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       srk_set_error("win256 attention: cannot reserve %zu bytes of LDS", lds);
       return SRK_E_LAUNCH;
@@ -187,14 +216,14 @@ int launch(const Win256Params& p, hipStream_t stream) {
   }
   const long long grid = (long long)p.B * p.nWh * p.nWw * p.nH;
   SRK_REQUIRE(grid > 0 && grid < (1LL << 31), SRK_E_SHAPE, "win256 attention: bad grid %lld", grid);
-  hipLaunchKernelGGL((win256_attn_fwd_kernel<NT, OCA>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((win256_attn_fwd_kernel<NT, OCA, TABLE>), dim3((unsigned)grid), dim3(256), lds, stream, p);
   return srk_check_launch("win256_attn_fwd");
 }
 
 }  // namespace
 
-int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* bias, bf16_t* out, int ldo, int B, int H, int W, int wh,
-                               int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream) {
+int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W,
+                               int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream) {
   SRK_REQUIRE(qkv && bias && out, SRK_E_NULL, "win256 attention: null pointer");
   SRK_REQUIRE(wh > 0 && ww > 0 && wh * ww == 256, SRK_E_UNSUPPORTED, "win256 attention: the window must hold 256 tokens (got %dx%d)", wh, ww);
   SRK_REQUIRE(B > 0 && H % wh == 0 && W % ww == 0, SRK_E_SHAPE, "win256 attention: %dx%d is not a multiple of the %dx%d window", H, W, wh, ww);
@@ -202,6 +231,12 @@ int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* 
               "win256 attention: bad layout nH=%d CA=%d ldq=%d ldo=%d", nH, CA, ldq, ldo);
   SRK_REQUIRE(sy >= 0 && sy < wh && sx >= 0 && sx < ww, SRK_E_SHAPE, "shift_size must in 0-window_size");
   Win256Params p;
+  p.table_rows = table_rows;
+  if (table_rows > 0) {
+    SRK_REQUIRE(wh == 16 && ww == 16 && table_rows == (overlap > 0 ? 39 * 39 : 31 * 31), SRK_E_UNSUPPORTED,
+                "win256 attention: table-indexed bias is built for 16x16 windows (961 rows; 1521 for the overlapping form), got %d rows",
+                table_rows);
+  }
   p.qkv = qkv; p.out = out; p.bias = bias; p.ldq = ldq; p.ldo = ldo; p.CA = CA; p.B = B; p.H = H; p.W = W; p.wh = wh; p.ww = ww;
   p.sy = sy; p.sx = sx; p.kh = wh; p.kw = ww; p.pad = 0; p.nWh = H / wh; p.nWw = W / ww; p.nH = nH; p.scale = scale;
   if (overlap > 0) {
@@ -209,7 +244,7 @@ int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* 
     SRK_REQUIRE(wh == 16 && ww == 16 && overlap == 8 && sy == 0 && sx == 0, SRK_E_UNSUPPORTED,
                 "overlapping cross-attention is built for 16x16 windows with overlap 8 (24x24 keys), no shift");
     p.kh = wh + overlap; p.kw = ww + overlap; p.pad = overlap / 2;
-    return launch<36, true>(p, stream);
+    return table_rows > 0 ? launch<36, true, true>(p, stream) : launch<36, true, false>(p, stream);
   }
-  return launch<16, false>(p, stream);
+  return table_rows > 0 ? launch<16, false, true>(p, stream) : launch<16, false, false>(p, stream);
 }

@@ -171,9 +171,9 @@ int srk_cab_add_ln(float* x, const uint16_t* conv, const float* gate, const floa
   return SRK_E_UNSUPPORTED;
 }
 
-int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* bias, uint16_t* out, int ldo, int B, int H, int W, int wh,
-                             int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap, srk_stream_t stream) {
-  return srk_launch_win256_attn_fwd(qkv, ldq, CA, bias, out, ldo, B, H, W, wh, ww, shift_y, shift_x, num_heads, scale, overlap,
+int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* bias, int table_rows, uint16_t* out, int ldo, int B, int H,
+                             int W, int wh, int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap, srk_stream_t stream) {
+  return srk_launch_win256_attn_fwd(qkv, ldq, CA, bias, table_rows, out, ldo, B, H, W, wh, ww, shift_y, shift_x, num_heads, scale, overlap,
                                     (hipStream_t)stream);
 }
 

@@ -13,7 +13,7 @@ stream, nothing else:
     every LayerNorm                   srk_layernorm_fwd / fused into the producing GEMM's epilogue
     qkv / proj / fc1 / fc2            srk_gemm_ex (persistent LDS-DMA GEMMs), Mlp as ONE kernel (srk_mlp_fused_fwd) at width 180
     (S)W-MSA 16x16 and OCAB           srk_win256_attention_fwd: roll / partition / unfold / reverse folded into the addresses,
-                                      shift mask arithmetic, rpi gathers pre-expanded to dense bias (negative rpi_oca wrapped)
+                                      shift mask arithmetic, bias table indexed in-kernel (closed-form rpi, negative rpi_oca wrapped)
     CAB                               two implicit-GEMM 3x3 convs (+GELU), srk_channel_gate, srk_cab_add_ln (+ norm2)
     RHAG conv, conv_after_body, head  implicit-GEMM 3x3 convs with residual / LeakyReLU / PixelShuffle / image epilogues
 
@@ -360,11 +360,7 @@ class HAT(nn.Module):
         C, CP = self.embed_dim, _rup(self.embed_dim, 64)
         hid = int(C * self.mlp_ratio)
         HP = _rup(hid, 64)
-        ws = self.window_size
-        wse = ws + int(self.overlap_ratio * ws)
         P: Dict[str, torch.Tensor] = {}
-        rpi_sa = self.relative_position_index_SA.to(device).reshape(-1)
-        rpi_oca = self.relative_position_index_OCA.to(device).reshape(-1)
         with torch.no_grad():
             for li, layer in enumerate(self.layers):
                 nH = self.heads[li]
@@ -388,8 +384,6 @@ class HAT(nn.Module):
                     pre = f"{li}.{bi}."
                     attn_pack(pre, blk.attn.qkv, blk.attn.proj)
                     mlp_pack(pre, blk.mlp)
-                    tab = blk.attn.relative_position_bias_table
-                    P[pre + "bias"] = tab[rpi_sa].reshape(ws * ws, ws * ws, nH).permute(2, 0, 1).float().contiguous()
                     cab = blk.conv_block.cab
                     P[pre + "Wc0"] = _pack_conv(cab[0].weight, 64, CP)
                     P[pre + "bc0"] = _pack_vec(cab[0].bias, 64)
@@ -404,8 +398,6 @@ class HAT(nn.Module):
                 pre = f"{li}.oca."
                 attn_pack(pre, oc.qkv, oc.proj)
                 mlp_pack(pre, oc.mlp)
-                idx = torch.where(rpi_oca < 0, rpi_oca + oc.relative_position_bias_table.shape[0], rpi_oca)     # negative-index wrap
-                P[pre + "bias"] = oc.relative_position_bias_table[idx].reshape(ws * ws, wse * wse, nH).permute(2, 0, 1).float().contiguous()
                 P[f"{li}.Wconv"] = _pack_conv(layer.conv.weight, CP, CP)
                 P[f"{li}.bconv"] = _pack_vec(layer.conv.bias, CP)
             P["Wcab"] = _pack_conv(self.conv_after_body.weight, CP, CP)
@@ -527,7 +519,8 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
             xn1, _, _, _ = ops.layernorm_fwd(cur, blk.norm1.weight, blk.norm1.bias, C_)                          # norm1 :290
             _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, xn1, P[pre + "Wqkv"], T, 3 * CA, CP, lda=CP, bias=P[pre + "bqkv"], outb=qkv, ldo=3 * CA)
             sh = blk.shift_size
-            check(L.srk_win256_attention_fwd(qkv.data_ptr(), 3 * CA, CA, P[pre + "bias"].data_ptr(), ao.data_ptr(), CA, B, H, W, ws, ws,
+            tab = blk.attn.relative_position_bias_table        # the kernel indexes the table itself (rpi in closed form)
+            check(L.srk_win256_attention_fwd(qkv.data_ptr(), 3 * CA, CA, tab.data_ptr(), tab.shape[0], ao.data_ptr(), CA, B, H, W, ws, ws,
                                              sh, sh, nH, scale, 0, st))                                           # :298-319
             x1 = torch.empty(T, CP, **f32)
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, ao, P[pre + "Wproj"], T, CP, CA, lda=CA, bias=P[pre + "bproj"], res=cur, outf=x1)
@@ -547,7 +540,8 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
         pre = f"{li}.oca."
         xn1, _, _, _ = ops.layernorm_fwd(cur, oc.norm1.weight, oc.norm1.bias, C_)
         _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, xn1, P[pre + "Wqkv"], T, 3 * CA, CP, lda=CP, bias=P[pre + "bqkv"], outb=qkv, ldo=3 * CA)
-        check(L.srk_win256_attention_fwd(qkv.data_ptr(), 3 * CA, CA, P[pre + "bias"].data_ptr(), ao.data_ptr(), CA, B, H, W, ws, ws, 0, 0, nH,
+        tab = oc.relative_position_bias_table
+        check(L.srk_win256_attention_fwd(qkv.data_ptr(), 3 * CA, CA, tab.data_ptr(), tab.shape[0], ao.data_ptr(), CA, B, H, W, ws, ws, 0, 0, nH,
                                          scale, oc.overlap_win_size - ws, st))
         x1 = torch.empty(T, CP, **f32)
         _gemm(st, _lib.LD_ROWS, _lib.EP_RES, ao, P[pre + "Wproj"], T, CP, CA, lda=CA, bias=P[pre + "bproj"], res=cur, outf=x1,
