@@ -47,7 +47,7 @@ __device__ __forceinline__ int region_label(int v, int n, int w, int s) { return
 // rpi_oca[p][k] = (yk - yp + ws - wse + 1)(ws + wse - 1) + (xk - xp + ws - wse + 1), wrapped by the table length when negative
 // (:896-918 + torch's negative indexing) -- instead of streaming a dense [256][NK] fp32 slab per workgroup from L2.
 template <int NT, bool OCA, bool TABLE>        // NT = key tiles of 16 (16: 256 keys, 36: 576 keys)
-__global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params p) {
+__global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void win256_attn_fwd_kernel(const Win256Params p) {
   constexpr int NK = NT * 16;
   constexpr int KW = OCA ? 24 : 16;                      // key-window width in table mode (16 x 16 / 24 x 24 windows)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params
 
   const float* bias_h = p.bias + (long long)h * 256 * NK;
   const bool masked = !OCA && (p.sy > 0 || p.sx > 0);
+  // interior windows of a shifted map have one region label throughout: only the last window row / column is masked
+  const bool need_mask = masked && (wy == p.nWh - 1 || wx == p.nWw - 1);
 
 #pragma unroll 1
   for (int qt = 0; qt < 4; ++qt) {
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params
     if (y >= p.H) y -= p.H;
     if (x >= p.W) x -= p.W;
     const long long qtok = tok0 + (long long)y * p.W + x;
-    const int qlab = masked ? region_label(wy * p.wh + qy, p.H, p.wh, p.sy) * 3 + region_label(wx * p.ww + qx, p.W, p.ww, p.sx) : 0;
+    const int qlab = need_mask ? region_label(wy * p.wh + qy, p.H, p.wh, p.sy) * 3 + region_label(wx * p.ww + qx, p.W, p.ww, p.sx) : 0;
     const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(p.qkv + qtok * p.ldq + h * 32 + 8 * g);
 
     // ---- S^T tiles -----------------------------------------------------------------------------------
@@ -124,41 +126,44 @@ __global__ __launch_bounds__(256) void win256_attn_fwd_kernel(const Win256Params
       s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     // ---- scale, bias, mask, row max ----------------------------------------------------------------------
+    // key kl = 16 j + 4 g + e of this lane: with c = 16 j + 4 g (a multiple of 4) the key row is c / KW and the key column
+    // c % KW + e (no carry: KW is a multiple of 4) -- one division per tile, not per element
     const float* brow = bias_h + (long long)ql * NK + 4 * g;
     float mx = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       float4 bv;
       if constexpr (TABLE) {
+        const int c = 16 * j + 4 * g;
+        const int ky = c / KW, kx0 = c - ky * KW;
         float be[4];
+        if constexpr (OCA) {
+          const int base = (ky - qy - 7) * 39 + (kx0 - qx - 7);                 // ws 16, wse 24: off = -7, 16 + 24 - 1 = 39
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int kl = 16 * j + 4 * g + e;
-          const int ky = kl / KW, kx = kl - ky * KW;
-          int idx;
-          if constexpr (OCA) {
-            idx = (ky - qy - 7) * 39 + (kx - qx - 7);                 // ws 16, wse 24: off = -7, 16 + 24 - 1 = 39
-            if (idx < 0) idx += p.table_rows;
-          } else {
-            idx = (qy - ky + 15) * 31 + (qx - kx + 15);
+          for (int e = 0; e < 4; ++e) {
+            int idx = base + e;
+            if (idx < 0) idx += p.table_rows;                                    // torch's negative-index wrap
+            be[e] = tab[idx];
           }
-          be[e] = tab[idx];
+        } else {
+          const int base = (qy - ky + 15) * 31 + (qx - kx0 + 15);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) be[e] = tab[base - e];
         }
         bv = make_float4(be[0], be[1], be[2], be[3]);
       } else {
         bv = *reinterpret_cast<const float4*>(brow + 16 * j);
       }
       float v0 = s[j][0] * p.scale + bv.x, v1 = s[j][1] * p.scale + bv.y, v2 = s[j][2] * p.scale + bv.z, v3 = s[j][3] * p.scale + bv.w;
-      if (masked) {
-        float vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int kl = 16 * j + 4 * g + e;
-          const int ky = kl / p.ww, kx = kl - ky * p.ww;
-          const int klab = region_label(wy * p.wh + ky, p.H, p.wh, p.sy) * 3 + region_label(wx * p.ww + kx, p.W, p.ww, p.sx);
-          if (klab != qlab) vv[e] += -100.0f;                       // hat_arch.py:939 (-100, not -inf)
-        }
-        v0 = vv[0]; v1 = vv[1]; v2 = vv[2]; v3 = vv[3];
+      if (need_mask) {                                                  // border windows only; any window shape with ww % 4 == 0
+        const int cm = 16 * j + 4 * g;
+        const int kym = cm / p.ww, kxm = cm - kym * p.ww;
+        const int lh = region_label(wy * p.wh + kym, p.H, p.wh, p.sy) * 3;
+        const int xb = wx * p.ww + kxm;
+        if (lh + region_label(xb, p.W, p.ww, p.sx) != qlab) v0 += -100.0f;          // hat_arch.py:939 (-100, not -inf)
+        if (lh + region_label(xb + 1, p.W, p.ww, p.sx) != qlab) v1 += -100.0f;
+        if (lh + region_label(xb + 2, p.W, p.ww, p.sx) != qlab) v2 += -100.0f;
+        if (lh + region_label(xb + 3, p.W, p.ww, p.sx) != qlab) v3 += -100.0f;
       }
       s[j] = f32x4_t{v0, v1, v2, v3};
       mx = fmaxf(mx, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
@@ -225,6 +230,7 @@ int launch(const Win256Params& p, hipStream_t stream) {
 int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W,
                                int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream) {
   SRK_REQUIRE(qkv && bias && out, SRK_E_NULL, "win256 attention: null pointer");
+  SRK_REQUIRE(ww % 4 == 0, SRK_E_UNSUPPORTED, "win256 attention: window width %d must be a multiple of 4", ww);
   SRK_REQUIRE(wh > 0 && ww > 0 && wh * ww == 256, SRK_E_UNSUPPORTED, "win256 attention: the window must hold 256 tokens (got %dx%d)", wh, ww);
   SRK_REQUIRE(B > 0 && H % wh == 0 && W % ww == 0, SRK_E_SHAPE, "win256 attention: %dx%d is not a multiple of the %dx%d window", H, W, wh, ww);
   SRK_REQUIRE(nH > 0 && CA == nH * 32 && ldq >= 3 * CA && ldq % 8 == 0 && ldo >= CA && ldo % 4 == 0, SRK_E_SHAPE,
