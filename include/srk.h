@@ -153,6 +153,19 @@ int srk_paired_crop_u8(const uint8_t* pool, const int64_t* lr_desc, const int64_
 int64_t srk_batch_psnr_workspace(int64_t per_image, int B);
 int srk_batch_psnr(const float* pred, const float* target, void* workspace, int B, int64_t per_image, float max_val, float* psnr,
                    float* psnr_sum, float* abs_sum, srk_stream_t stream);
+/* evaluate.py:24-29 on the device: psnr[b] = 20 log10(max_val / sqrt(max(mse_b, 1e-10))) of fp32 [B][per_image] images, NO
+ * clamp; mean = their batch mean (what the reference's psnr() returns).  psnr / mean may be null.  workspace:
+ * srk_eval_psnr_workspace bytes.  Fixed-order sums. */
+int64_t srk_eval_psnr_workspace(int64_t per_image, int B);
+int srk_eval_psnr(const float* x, const float* y, void* workspace, int B, int64_t per_image, float max_val, float* psnr, float* mean,
+                  srk_stream_t stream);
+/* pytorch_msssim.ssim(X, Y, data_range, size_average) as called at train.py:169 / evaluate.py:127,195: fp32 NCHW images, 11-tap
+ * Gaussian (sigma 1.5) VALID separable filter, K = (0.01, 0.03); per_image[b] = mean over channels of the per-channel map mean
+ * (size_average=False), mean = batch mean (size_average=True); either may be null.  H, W >= 11.  PARITY UNPINNED: the package
+ * is a third-party dependency absent from the reference tree (sr_environment.yml:165); restated from its published algorithm. */
+int64_t srk_ssim_workspace(int B, int C, int H, int W);
+int srk_ssim(const float* x, const float* y, void* workspace, int B, int C, int H, int W, float data_range, float* per_image, float* mean,
+             srk_stream_t stream);
 /* sum of squares of a flat fp32 gradient, ACCUMULATED into sumsq[0] (for clip_grad_norm_ :170) */
 int srk_grad_sumsq(const float* grads, int64_t n, float* sumsq, srk_stream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW step (:168-171, :303) on flat fp32 buffers.  The clip coefficient is

@@ -82,3 +82,41 @@ def test_validate_loop_matches_the_torch_form():
             ps += float(F.batch_psnr(out, hr.cuda()).sum()); ni += lr.size(0)
     assert abs(loss - tot / n) < 1e-6
     assert abs(psnr - ps / ni) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 50, 37), (2, 3, 128, 96), (1, 1, 11, 11), (4, 1, 500, 500)])
+def test_device_ssim_matches_the_torch_operator_form(shape):
+    """csrc/metrics.hip srk_ssim against metrics.ssim_torch on the CPU (itself checked against an independent scipy
+    evaluation in tests/test_cfg1_plumbing.py).  pytorch_msssim is absent: PARITY UNPINNED against the reference's own SSIM
+    numbers -- the algorithm is restated from the published package, not verified against its output."""
+    from tpu_superresolution_amd import metrics, ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(*shape, generator=g)
+    y = (x + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    want = metrics.ssim_torch(x, y, data_range=1.0, size_average=False)
+    per, mean = ops.ssim(x.cuda(), y.cuda(), 1.0)
+    assert float((per.cpu() - want).abs().max()) <= 2e-5
+    assert abs(float(mean) - float(want.mean())) <= 2e-5
+    per2, _ = ops.ssim(x.cuda(), y.cuda(), 1.0)
+    assert torch.equal(per, per2)                                        # fixed-order sums
+    # the module-level entry dispatches GPU tensors to the kernel, both reductions
+    assert abs(float(metrics.ssim(x.cuda(), y.cuda(), data_range=1.0)) - float(want.mean())) <= 2e-5
+    assert float((metrics.ssim(x.cuda(), y.cuda(), data_range=1.0, size_average=False).cpu() - want).abs().max()) <= 2e-5
+    assert float(metrics.ssim(x.cuda(), x.cuda(), data_range=1.0)) == pytest.approx(1.0, abs=1e-6)
+    # data_range 255 (the published default) scales C1 / C2
+    w255 = metrics.ssim_torch(x * 255, y * 255, data_range=255.0, size_average=True)
+    assert abs(float(metrics.ssim((x * 255).cuda(), (y * 255).cuda())) - float(w255)) <= 2e-5
+
+
+def test_device_eval_psnr_matches_evaluate_formula():
+    """evaluate.py:24-29 (no clamp, mse floored at 1e-10, batch mean) on the device; values from golden G12 ("restated from
+    text" by oracle/make_golden.py, not reference output: torchvision / pytorch_msssim keep evaluate.py from importing)."""
+    from tpu_superresolution_amd import metrics, ops
+    g = load_golden("g12_psnr")
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    per, mean = ops.eval_psnr(a.cuda(), b.cuda(), 1.0)
+    assert abs(float(mean) - float(g["eval_psnr"])) <= 1e-4
+    assert abs(float(mean) - O.eval_psnr(a, b)) <= 1e-4
+    assert abs(metrics.psnr(a.cuda(), b.cuda()) - float(g["eval_psnr"])) <= 1e-4
+    assert float(ops.eval_psnr(a.cuda(), a.cuda())[1]) == pytest.approx(100.0, abs=1e-3)      # floor 1e-10 -> 100 dB
+    assert float((metrics.batch_psnr(a.cuda(), b.cuda()).cpu() - torch.from_numpy(g["batch_psnr"])).abs().max()) <= 1e-4

@@ -23,8 +23,22 @@ def per_kernel(d, counter):
     return agg
 
 
+def kernels_digest():
+    """same digest as bench.py: ties the summary to the kernel sources it was measured on"""
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tpu_superresolution_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch_dir, write_dir, pattern, out = sys.argv[1:5]
+    steps = float(sys.argv[5]) if len(sys.argv) > 5 else None
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     rows, tot_b, tot_n = [], 0.0, 0
     for name in sorted(fe):
@@ -37,10 +51,17 @@ def main():
                      "write_bytes_per_launch": sum(wr[name]) / len(wr[name]) * 1024.0})
         tot_b += b * n
         tot_n += n
-    res = {"family": pattern, "avg_hbm_bytes_per_launch": tot_b / max(tot_n, 1), "launches_sampled": tot_n,
+    res = {"family": pattern, "kernels_sha": kernels_digest(), "avg_hbm_bytes_per_launch": tot_b / max(tot_n, 1), "launches_sampled": tot_n,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                      "(gfx950: FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)",
            "per_kernel": rows}
+    if steps:      # whole-step view: every launch of every matched kernel, divided by the number of profiled steps
+        total = 0.0
+        for name in fe:
+            if re.search(pattern, name) and name in wr:
+                total += (2.0 * sum(fe[name]) + sum(wr[name]) * len(fe[name]) / max(len(wr[name]), 1)) * 1024.0
+        res["hbm_bytes_per_step"] = total / steps
+        res["steps_profiled"] = steps
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "per_kernel"}))
     for r in rows:

@@ -89,6 +89,10 @@ _SIGNATURES = {
     "srk_paired_crop_u8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srk_batch_psnr_workspace": (_i64, [_i64, _i]),
     "srk_batch_psnr": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
+    "srk_eval_psnr_workspace": (_i64, [_i64, _i]),
+    "srk_eval_psnr": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
+    "srk_ssim_workspace": (_i64, [_i, _i, _i, _i]),
+    "srk_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "srk_grad_sumsq": (_i, [_vp, _i64, _vp, _vp]),
     "srk_adamw_clip_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "srk_gemm_ex": (_i, [C.POINTER(GemmArgs), _vp]),

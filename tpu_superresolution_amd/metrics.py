@@ -10,8 +10,10 @@
                  reference-produced fixture exists; tests check it against the closed form on cases with a known answer
                  (identical images -> 1, constant shift, scipy's gaussian_filter1d windows).
 
-These are the torch-operator forms (device-agnostic; evaluate.py / train.py run BASELINE cfg1 on the CPU).  The fused
-device-side validation metric of the SwinIR path is ``ops.batch_psnr`` (csrc/misc.hip).
+CPU tensors use the torch-operator forms below (evaluate.py / train.py run BASELINE cfg1 on the CPU).  fp32 GPU tensors go to
+the libsrk kernels: ``psnr`` -> ``srk_eval_psnr``, ``batch_psnr`` -> ``srk_batch_psnr``, ``ssim`` (4-D,
+H, W >= 11, default window) -> ``srk_ssim`` (csrc/metrics.hip, csrc/misc.hip): one fused pass, fixed-order sums, no per-pixel
+intermediates in HBM.
 """
 from __future__ import annotations
 
@@ -19,13 +21,23 @@ import torch
 import torch.nn.functional as F
 
 
+def _on_device(*ts) -> bool:
+    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
 def batch_psnr(pred: torch.Tensor, target: torch.Tensor, max_val: float = 1.0) -> torch.Tensor:
+    if _on_device(pred, target) and pred.size(0) <= 1024:
+        from . import ops
+        return ops.batch_psnr(pred.detach(), target.detach(), max_val)
     pred, target = pred.clamp(0.0, 1.0), target.clamp(0.0, 1.0)
     mse = ((pred - target) ** 2).reshape(pred.size(0), -1).mean(dim=1)
     return 20.0 * torch.log10(max_val / torch.sqrt(mse + 1e-8))
 
 
 def psnr(x: torch.Tensor, y: torch.Tensor, max_val: float = 1.0) -> float:
+    if _on_device(x, y) and x.size(0) <= 1024:
+        from . import ops
+        return float(ops.eval_psnr(x.detach(), y.detach(), max_val)[1])
     mse = torch.mean((x - y) ** 2, dim=[1, 2, 3]).clamp(min=1e-10)
     return float((20.0 * torch.log10(max_val / torch.sqrt(mse))).mean())
 
@@ -72,4 +84,9 @@ def ssim_torch(X: torch.Tensor, Y: torch.Tensor, data_range: float = 255.0, size
 
 def ssim(X: torch.Tensor, Y: torch.Tensor, data_range: float = 255.0, size_average: bool = True, **kw) -> torch.Tensor:
     """``pytorch_msssim.ssim`` signature (data_range default 255, as published)."""
+    if (_on_device(X, Y) and not kw and X.ndim == 4 and X.shape == Y.shape and X.shape[2] >= 11 and X.shape[3] >= 11 and X.size(0) <= 1024
+            and X.size(0) * X.size(1) < 65536):
+        from . import ops
+        per, mean = ops.ssim(X.detach(), Y.detach(), data_range)
+        return mean.reshape(()) if size_average else per
     return ssim_torch(X, Y, data_range=data_range, size_average=size_average, **kw)

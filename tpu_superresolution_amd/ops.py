@@ -206,6 +206,29 @@ def batch_psnr(pred: torch.Tensor, target: torch.Tensor, max_val: float = 1.0, p
     return out
 
 
+def eval_psnr(x: torch.Tensor, y: torch.Tensor, max_val: float = 1.0):
+    """evaluate.py:24-29 on the device -> (per-image PSNR [B], batch mean [1]) without a host sync."""
+    assert x.shape == y.shape and x.dtype == torch.float32 and y.dtype == torch.float32
+    x, y = x.contiguous(), y.contiguous()
+    B = x.shape[0]
+    per_image = x.numel() // B
+    ws = torch.empty(int(lib().srk_eval_psnr_workspace(per_image, B)), dtype=torch.uint8, device=x.device)
+    per, mean = torch.empty(B, dtype=torch.float32, device=x.device), torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib().srk_eval_psnr(_p(x), _p(y), _p(ws), B, per_image, float(max_val), _p(per), _p(mean), _stream()))
+    return per, mean
+
+
+def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0):
+    """pytorch_msssim.ssim semantics on the device (csrc/metrics.hip; restated, parity unpinned) -> (per-image [B], batch mean [1])."""
+    assert x.shape == y.shape and x.ndim == 4 and x.dtype == torch.float32 and y.dtype == torch.float32
+    x, y = x.contiguous(), y.contiguous()
+    B, Cc, H, W = x.shape
+    ws = torch.empty(max(4, int(lib().srk_ssim_workspace(B, Cc, H, W))), dtype=torch.uint8, device=x.device)
+    per, mean = torch.empty(B, dtype=torch.float32, device=x.device), torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib().srk_ssim(_p(x), _p(y), _p(ws), B, Cc, H, W, float(data_range), _p(per), _p(mean), _stream()))
+    return per, mean
+
+
 def l1_loss_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
     """-> (loss fp32 [1], d_pred | None, nonfinite int32 [1])   (finetune_swinir.py:66-67, :133-143)."""
     loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
