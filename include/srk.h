@@ -137,7 +137,8 @@ int srk_set_wgrad_workspace(void* workspace, int64_t bytes);
 /* Data path on the device (first slice): the paired transform of the training set -- ToImage +
  * ToDtype(scale=True), _ensure_3ch and paired_random_crop (finetune_swinir.py:80-110) -- from a pool of pre-decoded 8-bit
  * images in device memory.  pool: the images back to back, each [H][W][C] uint8 with C = 1 or 3.  lr_desc / hr_desc: B
- * descriptors of six int64 {byte offset in pool, H, W, C, top, left} in DEVICE memory; the caller draws (top, left) for the LR
+ * descriptors of six int64 {byte offset in pool, H, W, C | (wide << 8), top, left} in DEVICE memory (wide = 1: little-endian
+ * uint16 samples at an even byte offset, value = u16 / 65535); the caller draws (top, left) for the LR
  * side (the reference's random.randint pair, :101-102), the HR descriptor carries (top * scale, left * scale) and must lie
  * inside its image (the caller checks; the kernel does not).  lr_out: fp32 [B][3][P][P], hr_out: fp32 [B][3][P*scale][P*scale];
  * value = u8 / 255 in IEEE fp32, a gray image is repeated into three channels: bit-identical to the host transform. */

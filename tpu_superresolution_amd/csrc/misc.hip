@@ -696,16 +696,29 @@ __global__ __launch_bounds__(256) void crop_u8_kernel(const unsigned char* __res
                                                       float* __restrict__ out, int patch) {
   const long long* d = desc + 6 * (long long)blockIdx.y;
   const unsigned char* img = pool + d[0];
-  const int W = (int)d[2], C = (int)d[3], top = (int)d[4], left = (int)d[5];
+  // channel field: low byte = channels (1 / 3); bit 8 set = 16-bit samples (little-endian uint16, value / 65535: what
+  // torchvision's ToDtype(scale=True) does for uint16 -- pil_to_tensor01 in sr_datasets.py)
+  const int W = (int)d[2], C = (int)(d[3] & 0xff), wide = (int)((d[3] >> 8) & 1), top = (int)d[4], left = (int)d[5];
   float* o = out + (long long)blockIdx.y * 3 * patch * patch;
   const int n = patch * patch;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int y = i / patch, x = i - y * patch;
-    const unsigned char* px = img + ((long long)(top + y) * W + (left + x)) * C;
-    const float c0 = (float)px[0] / 255.0f;
+    const long long e = ((long long)(top + y) * W + (left + x)) * C;
+    float c0, c1, c2;
+    if (wide) {
+      const unsigned short* px = reinterpret_cast<const unsigned short*>(img) + e;
+      c0 = (float)px[0] / 65535.0f;
+      c1 = C == 1 ? c0 : (float)px[1] / 65535.0f;
+      c2 = C == 1 ? c0 : (float)px[2] / 65535.0f;
+    } else {
+      const unsigned char* px = img + e;
+      c0 = (float)px[0] / 255.0f;
+      c1 = C == 1 ? c0 : (float)px[1] / 255.0f;
+      c2 = C == 1 ? c0 : (float)px[2] / 255.0f;
+    }
     o[i] = c0;
-    o[n + i] = C == 1 ? c0 : (float)px[1] / 255.0f;
-    o[2 * n + i] = C == 1 ? c0 : (float)px[2] / 255.0f;
+    o[n + i] = c1;
+    o[2 * n + i] = c2;
   }
 }
 

@@ -75,6 +75,16 @@ class DevicePoolLoader:
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         perm = torch.randperm(len(self.pool), generator=g).tolist()
         mine = perm[self.rank:len(perm) - len(perm) % self.world:self.world] if self.world > 1 else perm
+        if getattr(self.pool, "num_shards", 1) > 1:
+            # sharded pool (pinned host shards, two resident on the device): walk the epoch shard by shard -- shuffled order of
+            # shards, shuffled images inside each -- so that the copy of the next shard overlaps the steps on this one
+            order = torch.randperm(self.pool.num_shards, generator=g).tolist()
+            by_shard = {s: [i for i in mine if self.pool.shard_of(i) == s] for s in order}
+            for s in order:
+                idx = by_shard[s]
+                for b in range(len(idx) // self.batch_size):
+                    yield self.pool.sample(idx[b * self.batch_size:(b + 1) * self.batch_size])
+            return
         for b in range(len(self)):
             yield self.pool.sample(mine[b * self.batch_size:(b + 1) * self.batch_size])
 
@@ -147,7 +157,10 @@ def main(argv=None):
     ap.add_argument("--grad_clip", type=float, default=1.0)
     ap.add_argument("--drop_path_rate", type=float, default=0.1)      # additive
     ap.add_argument("--gpu_data", action="store_true",
-                    help="additive: decode the 8-bit training set once into GPU memory and crop/convert on the device")
+                    help="additive: decode the training set once and crop/convert on the device")
+    ap.add_argument("--gpu_data_shard_mb", type=int, default=0,
+                    help="additive, with --gpu_data: keep the decoded set in pinned host shards of this size and prefetch them "
+                         "to the device one ahead (0 = whole set resident on the device)")
     args = ap.parse_args(argv)
 
     rank, world, local = init_from_env()
@@ -171,10 +184,11 @@ def main(argv=None):
     if args.gpu_data:
         from .sr_datasets import DevicePairPool
         raw = Shuffled2DPaired(args.data_root, split="train", scale=args.scale, transform_pair=None)
-        pool = DevicePairPool((raw[i] for i in range(len(raw))), args.lr_patch, scale_int, device=device)
+        pool = DevicePairPool((raw[i] for i in range(len(raw))), args.lr_patch, scale_int, device=device,
+                              shard_bytes=(args.gpu_data_shard_mb << 20) or None)
         train_loader = sampler = DevicePoolLoader(pool, args.batch_size, rank, world, args.seed)
         if rank == 0:
-            print(f"[gpu_data] {len(pool)} pairs, {pool.pool.numel() / 2**20:.1f} MiB of uint8 on the device")
+            print(f"[gpu_data] {len(pool)} pairs in {pool.num_shards} shard(s), {sum(t.numel() for t in pool._host) / 2**20:.1f} MiB decoded")
     valid_loader = make_loader(valid_ds, max(1, args.batch_size // 2), args.workers, pin=not args.no_pin, shuffle=False,
                                drop_last=False, persistent=not args.no_persistent)
 
