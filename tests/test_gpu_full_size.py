@@ -63,7 +63,9 @@ def test_train_step_is_deterministic_and_gradients_are_linear(cfg3):
     # the large weight gradients are reduced in a fixed order (bit-reproducible); the small reductions -- bias, LayerNorm
     # gamma/beta, relative-position-bias and conv_first gradients -- still use fp32 atomics and differ in the last bits
     # between runs (tools/parity_probe.py lists them), which the clip coefficient then spreads to every weight
-    assert abs(l1[0] - l2[0]) <= 1e-6 * abs(l1[0]) and abs(l1[1] - l2[1]) <= 1e-5 * abs(l1[1])
+    # (the forward is bit-reproducible -- tools/parity_probe.py -- but the L1 loss sums its workgroup partials with fp32 atomics:
+    # the scalar differs in the last bits between runs)
+    assert abs(l1[0] - l2[0]) <= 1e-5 * abs(l1[0]) and abs(l1[1] - l2[1]) <= 1e-5 * abs(l1[1])
     # ... but Adam's first steps move every weight by ~lr * sign(g): where g is zero up to that last-bit noise the sign,
     # and with it one step of size lr, differs.  Bound: 2 steps x 2 lr per element, and few elements affected (measured 1 %).
     diffs = torch.cat([(s1[k] - s2[k]).abs().flatten() for k in s1 if s1[k].dtype.is_floating_point])
