@@ -175,15 +175,83 @@ def gen_g13():
     print("G13 cfg4 params", n_params, "keys", len(m.state_dict()), "mean", yn.mean(), "std", yn.std(), "max", np.abs(yn).max())
 
 
+DAT_TINY = dict(img_size=32, in_chans=3, embed_dim=48, split_size=(8, 32), depth=(3, 2), num_heads=(4, 4), expansion_factor=2.0,
+                upscale=2, img_range=1.0, resi_connection="1conv", upsampler="pixelshuffle")
+
+
+def gen_g14():
+    """G14: DAT (dat_arch.py imports with the timm stand-in).  Index tables bit-exact, a tiny DAT end to end (eval: BatchNorm with
+    running statistics) incl. a shifted spatial block (rg 0, b 2), a channel-attention block and both window orientations, the
+    blocks in isolation, and probes of the full DAT x4 (BASELINE cfg5) forward."""
+    from oracle import dat_oracle as DO
+    da = import_reference("dat_arch")
+    cfg = DO.DATConfig(**DAT_TINY)
+    sd = DO.random_state_dict(cfg, seed=14, scale=2.0)
+    torch.manual_seed(0)
+    m = da.DAT(**cfg.kwargs())
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), [(a, b) for a, b in zip(ref_sd.keys(), sd.keys()) if a != b][:5]
+    for k in sd:      # the reference's own buffers equal the closed forms
+        if k.endswith(("rpe_biases", "relative_position_index", "attn_mask_0", "attn_mask_1")):
+            assert torch.equal(ref_sd[k].to(sd[k].dtype), sd[k]), k
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    m.eval()
+    arrays = dict(weight_seed=np.array(14), weight_scale=np.array(2.0),
+                  weight_sha1=np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))))
+    blk0 = m.layers[0].blocks[0].attn.attns
+    arrays["rpi_8x32"] = blk0[0].relative_position_index.numpy()
+    arrays["rpi_32x8"] = blk0[1].relative_position_index.numpy()
+    arrays["rpe_8x32"] = blk0[0].rpe_biases.numpy()
+    mk = m.layers[0].blocks[2].attn.calculate_mask(32, 64)
+    arrays["mask0_32x64"] = (mk[0].numpy() != 0).astype(np.uint8)
+    arrays["mask1_32x64"] = (mk[1].numpy() != 0).astype(np.uint8)
+    for hw in ((32, 32), (32, 64)):
+        x = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(hw[0] * 100 + hw[1]))
+        with torch.no_grad():
+            y = m(x)
+        arrays[f"x_{hw[0]}x{hw[1]}"] = x.numpy()
+        arrays[f"y_{hw[0]}x{hw[1]}"] = y.numpy()
+    xt = torch.randn(1, 32 * 64, 48, generator=torch.Generator().manual_seed(5))        # 32x64: masks computed on the fly (:404-407)
+    xs = torch.randn(1, 32 * 32, 48, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        arrays["blk.x_seed"] = np.array(5)
+        arrays["blk.xs_seed"] = np.array(6)
+        arrays["blk.spatial_shifted"] = m.layers[0].blocks[2](xt, (32, 64)).numpy()
+        arrays["blk.spatial_plain"] = m.layers[0].blocks[0](xs, (32, 32)).numpy()
+        arrays["blk.channel"] = m.layers[0].blocks[1](xs, (32, 32)).numpy()
+        arrays["blk.shifted_rg1"] = m.layers[1].blocks[0](xs, (32, 32)).numpy()
+        arrays["blk.sgfn"] = m.layers[0].blocks[0].ffn(xs, 32, 32).numpy()
+    save("g14_dat_tiny", **arrays)
+    cfg = DO.DATConfig.sr_x4()
+    sd = DO.random_state_dict(cfg, seed=42, scale=1.0)
+    m = da.DAT(**cfg.kwargs())
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    xin = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        yn = m(xin).numpy()
+    pg = np.random.RandomState(1).randint(0, yn.size, size=64)
+    n_params = sum(p.numel() for p in m.parameters())
+    save("g14_dat_cfg5_probe", probe_index=pg, probe_value=yn.reshape(-1)[pg], mean=np.array(yn.mean()), std=np.array(yn.std()),
+         sha1=np.array(sha1(yn)), shape=np.array(yn.shape), n_params=np.array(n_params), n_keys=np.array(len(m.state_dict())),
+         weight_seed=np.array(42), weight_scale=np.array(1.0), input_seed=np.array(0), batch=np.array(1))
+    print("G14 cfg5 params", n_params, "keys", len(m.state_dict()), "mean", yn.mean(), "std", yn.std(), "max", np.abs(yn).max())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-g14" in sys.argv:
+        return gen_g14()
     if "--only-g11" in sys.argv:
         return gen_g11()
     if "--only-g13" in sys.argv:
         return gen_g13()
     gen_g11()
     gen_g13()
+    gen_g14()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------

@@ -278,3 +278,73 @@ def test_g13_hat_cfg4_schema_and_probe():
     assert tuple(y.shape) == tuple(g["shape"])
     assert np.abs(y.reshape(-1)[g["probe_index"]] - g["probe_value"]).max() < 2e-5
     assert abs(float(y.mean()) - float(g["mean"])) < 1e-5 and abs(float(y.std()) - float(g["std"])) < 1e-5
+
+
+# ---- G14: DAT (reference modules/dat_arch.py; fixtures by oracle/make_golden.py::gen_g14) -----------------------------------
+DAT_TINY = dict(img_size=32, in_chans=3, embed_dim=48, split_size=(8, 32), depth=(3, 2), num_heads=(4, 4), expansion_factor=2.0,
+                upscale=2, img_range=1.0, resi_connection="1conv", upsampler="pixelshuffle")
+
+
+def dat_tiny_weights():
+    from oracle import dat_oracle as DO
+    g = load_golden("g14_dat_tiny")
+    cfg = DO.DATConfig(**DAT_TINY)
+    sd = DO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g["weight_sha1"]), "DAT weight generator drifted from the one the fixtures were made with"
+    return g, cfg, sd
+
+
+def test_g14_dat_index_tables_bit_exact():
+    from oracle import dat_oracle as DO
+    g = load_golden("g14_dat_tiny")
+    assert np.array_equal(DO.rect_rpi(8, 32), g["rpi_8x32"]) and np.array_equal(DO.rect_rpi(32, 8), g["rpi_32x8"])
+    assert np.array_equal(DO.rpe_offsets(8, 32), g["rpe_8x32"])
+    assert np.array_equal((DO.rect_shift_mask(32, 64, 8, 32, 4, 16) != 0).astype(np.uint8), g["mask0_32x64"])
+    assert np.array_equal((DO.rect_shift_mask(32, 64, 32, 8, 16, 4) != 0).astype(np.uint8), g["mask1_32x64"])
+    # img2windows (dat_arch.py:15-23) as a gather map, against the closed form of the reference's view/permute
+    idx = DO.rect_window_token_index(16, 64, 8, 32, 0, 0)
+    img = np.arange(16 * 64).reshape(16, 64)
+    want = img.reshape(2, 8, 2, 32).transpose(0, 2, 1, 3).reshape(4, 256)
+    assert np.array_equal(idx, want)
+    assert [DO.is_shifted(0, b) for b in range(6)] == [False, False, True, False, False, False]
+    assert [DO.is_shifted(1, b) for b in range(6)] == [True, False, False, False, True, False]
+
+
+def test_g14_dat_tiny_end_to_end_and_blocks():
+    from oracle import dat_oracle as DO
+    g, cfg, sd = dat_tiny_weights()
+    for hw in ((32, 32), (32, 64)):
+        x = torch.from_numpy(g[f"x_{hw[0]}x{hw[1]}"])
+        with torch.no_grad():
+            y = DO.dat_forward(sd, cfg, x)
+        ref = torch.from_numpy(g[f"y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape == (1, 3, hw[0] * 2, hw[1] * 2)
+        assert (y - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), hw
+    xt = torch.randn(1, 32 * 64, 48, generator=torch.Generator().manual_seed(int(g["blk.x_seed"])))
+    xs = torch.randn(1, 32 * 32, 48, generator=torch.Generator().manual_seed(int(g["blk.xs_seed"])))
+    with torch.no_grad():
+        tol = lambda r: 2e-5 * max(1.0, float(torch.from_numpy(r).abs().max()))
+        assert (DO.datb(xt, 32, 64, sd, "layers.0.blocks.2.", cfg, 4, 0, 2) - torch.from_numpy(g["blk.spatial_shifted"])).abs().max() < tol(g["blk.spatial_shifted"])
+        assert (DO.datb(xs, 32, 32, sd, "layers.0.blocks.0.", cfg, 4, 0, 0) - torch.from_numpy(g["blk.spatial_plain"])).abs().max() < tol(g["blk.spatial_plain"])
+        assert (DO.datb(xs, 32, 32, sd, "layers.0.blocks.1.", cfg, 4, 0, 1) - torch.from_numpy(g["blk.channel"])).abs().max() < tol(g["blk.channel"])
+        assert (DO.datb(xs, 32, 32, sd, "layers.1.blocks.0.", cfg, 4, 1, 0) - torch.from_numpy(g["blk.shifted_rg1"])).abs().max() < tol(g["blk.shifted_rg1"])
+        assert (DO.sgfn(xs, 32, 32, sd, "layers.0.blocks.0.ffn.") - torch.from_numpy(g["blk.sgfn"])).abs().max() < tol(g["blk.sgfn"])
+
+
+def test_g14_dat_cfg5_schema_and_probe():
+    """DAT x4 (BASELINE cfg5): 14 802 051 parameters / 2 116 keys; one 64x64 forward against the reference's probes."""
+    from oracle import dat_oracle as DO
+    g = load_golden("g14_dat_cfg5_probe")
+    cfg = DO.DATConfig.sr_x4()
+    sd = DO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    assert len(sd) == int(g["n_keys"]) == 2116
+    n_params = sum(v.numel() for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked", "rpe_biases",
+                                                                       "relative_position_index", "attn_mask_0", "attn_mask_1")))
+    assert n_params == int(g["n_params"]) == 14802051
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    with torch.no_grad():
+        y = DO.dat_forward(sd, cfg, x).numpy()
+    assert tuple(y.shape) == tuple(g["shape"])
+    assert np.abs(y.reshape(-1)[g["probe_index"]] - g["probe_value"]).max() < 2e-5
+    assert abs(float(y.mean()) - float(g["mean"])) < 1e-5 and abs(float(y.std()) - float(g["std"])) < 1e-5
