@@ -9,10 +9,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write", "gemm_stream",
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write", "gemm_stream|mlp_fused",
                        f"{P}/{tag}_pmc_linear_gemm_stream_traffic.json"], stdout=subprocess.DEVNULL)
+# whole step: every kernel of the 4 profiled steps (3 timed + 1 warm-up), bytes per step
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write", ".",
+                       f"{P}/{tag}_pmc_step_traffic.json", "4"], stdout=subprocess.DEVNULL)
+for cfg in ("cfg2", "cfg4"):
+    if os.path.exists(f"{G}/m_bench_{cfg}.json"):
+        shutil.copy(f"{G}/m_bench_{cfg}.json", f"{P}/{tag}_bench_line_{cfg}.json")
+    st = glob.glob(f"{G}/m_prof_{cfg}/*/*_kernel_stats.csv")
+    if st:
+        shutil.copy(st[0], f"{P}/{tag}_{cfg}_kernel_stats.csv")
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write",
                        "wgrad|attn|taps|gemm_kernel<1|imghead|smallconv", f"{P}/{tag}_pmc_other_kernels_traffic.json"], stdout=subprocess.DEVNULL)
 stats = glob.glob(f"{G}/m_prof/*/*_kernel_stats.csv")[0]
@@ -22,12 +31,12 @@ shutil.copy(f"{G}/m_prof_bench.json", f"{P}/{tag}_final_bench_line_under_rocprof
 body = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), f"{G}/m_prof", "25"], text=True)
 tot, n = 0.0, 0
 for r in csv.DictReader(open(stats)):
-    if "gemm_stream" in r["Name"]:
+    if "gemm_stream" in r["Name"] or "mlp_fused" in r["Name"]:
         tot += float(r["TotalDurationNs"])
         n += int(r["Calls"])
 d = json.load(open(f"{G}/m_bench.json"))
 traffic = json.load(open(f"{P}/{tag}_pmc_linear_gemm_stream_traffic.json"))["avg_hbm_bytes_per_launch"]
-hdr = f"""# rocprofv3 --kernel-trace --stats of the default bench command (round 1, final)
+hdr = f"""# rocprofv3 --kernel-trace --stats of the default bench command ({tag})
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` (25 train steps of cfg3,
 bs 32, incl. 5 warm-up; the HIP-event probe brackets every {d['roofline'].get('sampled_every', 1)}th launch of the roofline family during the 20 timed steps).
@@ -42,7 +51,9 @@ tile, K split>`; `gemm_kernel<loader, epilogue, NT, narrow>` (loader 1 conv3x3 /
 epilogue 0 bf16, 1 qkv, 2 proj+residual+LN2, 3 GELU, 4 residual+next LN, 5 dGELU, 6 LeakyReLU, 7 PixelShuffle, 8 image,
 10 residual->bf16, 11 dLeakyReLU, 12 f32+bf16, 13 fused LayerNorm backward.
 
-The roofline kernel family of bench.py is `gemm_stream*_kernel` (csrc/gemm_stream.hip): {n / 25:.0f} launches/step, average duration in
+`mlp_fused_fwd_kernel` (csrc/gemm_stream.hip) replaces the fc1 (`<3, ...>`) and fc2 (`<4, ...>`) forward launches of round 1.
+
+The roofline kernel family of bench.py is `gemm_stream*_kernel` + `mlp_fused_fwd_kernel` (csrc/gemm_stream.hip): {n / 25:.0f} launches/step, average duration in
 this trace {tot / n / 1e3:.1f} us over {n} launches; bench.py's HIP-event probe in the un-profiled run: {d['roofline']['avg_launch_us']:.1f} us
 (`roofline.avg_launch_us`, every {d['roofline'].get('sampled_every', 1)}th launch sampled; the event pair itself adds ~3 us to a bracketed launch).
 PMC HBM traffic of the family: `{tag}_pmc_linear_gemm_stream_traffic.json` ({traffic / 1e6:.0f} MB/launch measured vs {d['roofline']['algorithmic_bytes_per_launch'] / 1e6:.0f} MB
