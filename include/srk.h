@@ -188,6 +188,7 @@ enum { SRK_EP_BF16 = 0,       /* outb = bf16(v + bias) */
        SRK_EP_LRELU = 6,      /* outb = bf16(leaky_relu(v + bias, scale)) */
        SRK_EP_PS = 7,         /* conv + PixelShuffle(r): W rows permuted to (i*r + j)*Cs + c; store is the shuffled NHWC tensor */
        SRK_EP_IMG = 8,        /* N == 16: outf NCHW image [B][Cimg][Hc][Wc] = v * inv_range + mean[c] (crop) */
+       SRK_EP_PS_IMG = 9,     /* N == 16: conv + PixelShuffle(r) straight into the NCHW image (UpsampleOneStep), n = c*r*r + i*r + j */
        SRK_EP_RES_BF16 = 10,  /* outb = bf16(res + v + bias) */
        SRK_EP_MLP_FUSED = 100 /* (reserved; see srk_mlp_fused_fwd) */ };
 typedef struct {
@@ -232,9 +233,35 @@ int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* 
 size_t srk_channel_gate_workspace(int B, int HW, int CP);
 int srk_channel_gate(const uint16_t* x, void* workspace, const float* w1, const float* b1, const float* w2, const float* b2, float out_scale,
                      float* gate, int B, int HW, int C, int CP, int S, srk_stream_t stream);
+/* same with the hidden activation selectable: act 0 ReLU (HAT), 1 GELU (DAT's channel_interaction, dat_arch.py:315-321, BatchNorm folded) */
+int srk_channel_gate_act(const uint16_t* x, void* workspace, const float* w1, const float* b1, const float* w2, const float* b2, float out_scale,
+                         float* gate, int B, int HW, int C, int CP, int S, int act, srk_stream_t stream);
 /* HAB.forward :322-323: x += conv * gate[sample] in place (fp32 [rows][CP]) and, if xn != null, xn = bf16(LayerNorm(x)) */
 int srk_cab_add_ln(float* x, const uint16_t* conv, const float* gate, const float* gamma, const float* beta, uint16_t* xn, int64_t rows,
                    int rows_per_sample, int C, int CP, srk_stream_t stream);
+
+/* ---- DAT (reference dat_arch.py), inference pieces; token-major bf16 [T][ld], channels padded per head to 32 -------------------------
+ * Depth-wise 3x3 conv, pad 1, over C8*8 channels of x (column 0 of the slice given): out = act((conv(x)) * scale + shift) * mul.
+ * w fp32 [C8*8][9]; scale / shift fp32 [C8*8] carry the conv bias and an inference BatchNorm folded by the caller
+ * (dat_arch.py:310-314, :463-467); act 0 none / 1 GELU; mul (optional) is SGFN's x1 in x1 * DWconv(LN(x2)) (:48-54). */
+int srk_dwconv3x3(const uint16_t* x, int ldx, const float* w, const float* scale, const float* shift, const uint16_t* mul, int ldm, uint16_t* out,
+                  int ldo, int B, int H, int W, int C8, int act, srk_stream_t stream);
+/* LayerNorm (eps 1e-5) over C channels of a bf16 row slice -> bf16 [rows][ldo], columns C..CP_out written as zero (SpatialGate.norm :46) */
+int srk_rowln_bf16(const uint16_t* x, int ldx, const float* gamma, const float* beta, uint16_t* out, int ldo, int64_t rows, int C, int CP_out,
+                   srk_stream_t stream);
+/* spatial_interaction (:322-327, :475-480): gate[t] = sigmoid(b3 + w3 . gelu(W0 x_t + b0)); W0 fp32 [S][CP] (BatchNorm folded, zero at pads) */
+int srk_spatial_gate(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, float b3, int S, float* gate, int64_t rows,
+                     int CP, srk_stream_t stream);
+/* out = a * ga + b * gb with one gate per token (tgate [rows]) and one per (sample, channel) (cgate [B][CP]); tok_gate_on_a selects
+ * which operand takes the token gate (:430-436 spatial block: 0; :518-524 channel block: 1).  Gates are post-sigmoid. */
+int srk_dual_gate_combine(const uint16_t* a, const uint16_t* b, const float* cgate, const float* tgate, uint16_t* out, int64_t rows,
+                          int rows_per_sample, int CP, int tok_gate_on_a, srk_stream_t stream);
+/* Adaptive_Channel_Attention core (:481-505): per sample and head, q / k columns L2-normalised over the N tokens, logits
+ * (d x d) * temperature[h], softmax, applied to v.  qkv bf16 [B*N][ldq] (q | k | v at 0 / CA / 2 CA, head h at +32 h); out bf16
+ * [B*N][ldo] (head-padded channels).  Fixed-order reductions. */
+size_t srk_channel_attention_workspace(int B, int N, int num_heads);
+int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* temperature, void* workspace, uint16_t* out, int ldo, int B,
+                              int N, int num_heads, int head_dim, srk_stream_t stream);
 
 /* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
 enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1,          /* classical SR           (network_swinir.py:740-745, :813-817) */

@@ -5,8 +5,9 @@ is the host side: ctypes binding, the nn.Module mirror of the reference's constr
 the fused optimizer and the data-parallel wrapper -- plus the reference's other entry points
 (train.py / evaluate.py / finetune_swinir.py) and the MS_ResUNet plumbing model (stock torch operators).
 """
+from .dat_arch import DAT  # noqa: F401
 from .hat_arch import HAT  # noqa: F401
 from .ms_resunet import MS_ResUNet, MSResUNet  # noqa: F401
 from .network_swinir import SwinIR, window_partition, window_reverse  # noqa: F401
 
-__all__ = ["SwinIR", "window_partition", "window_reverse", "MS_ResUNet", "MSResUNet", "HAT"]
+__all__ = ["SwinIR", "window_partition", "window_reverse", "MS_ResUNet", "MSResUNet", "HAT", "DAT"]

@@ -47,7 +47,7 @@ class GemmArgs(C.Structure):
 
 
 LD_ROWS, LD_CONV3 = 0, 1
-EP_BF16, EP_GELU, EP_RES, EP_LRELU, EP_PS, EP_IMG, EP_RES_BF16 = 0, 3, 4, 6, 7, 8, 10
+EP_BF16, EP_GELU, EP_RES, EP_LRELU, EP_PS, EP_IMG, EP_PS_IMG, EP_RES_BF16 = 0, 3, 4, 6, 7, 8, 9, 10
 
 UPSAMPLER_PIXELSHUFFLE = 1
 UPSAMPLER_PIXELSHUFFLEDIRECT = 2
@@ -102,6 +102,13 @@ _SIGNATURES = {
     "srk_win256_attention_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "srk_channel_gate_workspace": (_sz, [_i, _i, _i]),
     "srk_channel_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_channel_gate_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_dwconv3x3": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_rowln_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "srk_spatial_gate": (_i, [_vp, _i, _vp, _vp, _vp, _f, _i, _vp, _i64, _i, _vp]),
+    "srk_dual_gate_combine": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "srk_channel_attention_workspace": (_sz, [_i, _i, _i]),
+    "srk_channel_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srk_cab_add_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_swinir_plan_create": (_i, [C.POINTER(SwinIRConfig), C.POINTER(_vp)]),
     "srk_swinir_plan_destroy": (None, [_vp]),

@@ -233,7 +233,9 @@ int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* 
   SRK_REQUIRE(ww % 4 == 0, SRK_E_UNSUPPORTED, "win256 attention: window width %d must be a multiple of 4", ww);
   SRK_REQUIRE(wh > 0 && ww > 0 && wh * ww == 256, SRK_E_UNSUPPORTED, "win256 attention: the window must hold 256 tokens (got %dx%d)", wh, ww);
   SRK_REQUIRE(B > 0 && H % wh == 0 && W % ww == 0, SRK_E_SHAPE, "win256 attention: %dx%d is not a multiple of the %dx%d window", H, W, wh, ww);
-  SRK_REQUIRE(nH > 0 && CA == nH * 32 && ldq >= 3 * CA && ldq % 8 == 0 && ldo >= CA && ldo % 4 == 0, SRK_E_SHAPE,
+  // CA is the column distance between the q, k and v blocks of a row; a caller may run a SUBSET of the heads (DAT's two branches take
+  // heads 0..nH/2-1 and nH/2..nH-1 with different window shapes) by offsetting qkv / out by 32 * first_head
+  SRK_REQUIRE(nH > 0 && CA >= nH * 32 && CA % 32 == 0 && ldq >= 3 * CA && ldq % 8 == 0 && ldo >= nH * 32 && ldo % 4 == 0, SRK_E_SHAPE,
               "win256 attention: bad layout nH=%d CA=%d ldq=%d ldo=%d", nH, CA, ldq, ldo);
   SRK_REQUIRE(sy >= 0 && sy < wh && sx >= 0 && sx < ww, SRK_E_SHAPE, "shift_size must in 0-window_size");
   Win256Params p;

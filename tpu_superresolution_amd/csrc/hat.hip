@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void token_mean_partial_kernel(const bf16_t* _
 __global__ __launch_bounds__(256) void channel_gate_kernel(const float* __restrict__ partial, int nchunk, int HW, int C, int CP, int S,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ w2, const float* __restrict__ b2, float out_scale,
-                                                           float* __restrict__ gate) {
+                                                           float* __restrict__ gate, int act) {
   __shared__ float mean[256];
   __shared__ float z[64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void channel_gate_kernel(const float* __restri
   if (tid < S) {
     float a = b1[tid];
     for (int c = 0; c < C; ++c) a += w1[tid * C + c] * mean[c];
-    z[tid] = a > 0.f ? a : 0.f;
+    z[tid] = act == 1 ? gelu_f(a) : (a > 0.f ? a : 0.f);
   }
   __syncthreads();
   if (tid < CP) {
@@ -139,15 +139,22 @@ extern "C" {
 
 size_t srk_channel_gate_workspace(int B, int HW, int CP) { return (size_t)B * ((HW + TM_ROWS - 1) / TM_ROWS) * CP * sizeof(float); }
 
+int srk_channel_gate_act(const uint16_t* x, void* workspace, const float* w1, const float* b1, const float* w2, const float* b2, float out_scale,
+                         float* gate, int B, int HW, int C, int CP, int S, int act, srk_stream_t stream);
 int srk_channel_gate(const uint16_t* x, void* workspace, const float* w1, const float* b1, const float* w2, const float* b2, float out_scale,
                      float* gate, int B, int HW, int C, int CP, int S, srk_stream_t stream) {
+  return srk_channel_gate_act(x, workspace, w1, b1, w2, b2, out_scale, gate, B, HW, C, CP, S, 0, stream);
+}
+
+int srk_channel_gate_act(const uint16_t* x, void* workspace, const float* w1, const float* b1, const float* w2, const float* b2, float out_scale,
+                         float* gate, int B, int HW, int C, int CP, int S, int act, srk_stream_t stream) {
   SRK_REQUIRE(x && workspace && w1 && b1 && w2 && b2 && gate, SRK_E_NULL, "channel_gate: null pointer");
   SRK_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && C <= CP && CP % 64 == 0 && CP <= 256 && S > 0 && S <= 64, SRK_E_SHAPE,
               "channel_gate: bad shape B=%d HW=%d C=%d CP=%d S=%d", B, HW, C, CP, S);
   const int nchunk = (HW + TM_ROWS - 1) / TM_ROWS;
   hipLaunchKernelGGL(token_mean_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, static_cast<float*>(workspace), HW, CP);
   hipLaunchKernelGGL(channel_gate_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace), nchunk, HW, C, CP, S,
-                     w1, b1, w2, b2, out_scale, gate);
+                     w1, b1, w2, b2, out_scale, gate, act);
   return srk_check_launch("channel_gate");
 }
 
@@ -192,7 +199,7 @@ int srk_gemm_ex(const srk_gemm_args* a, srk_stream_t stream) {
   p.xn_beta = a->xn_beta; p.xn_C = a->xn_C;
   p.flops = 2.0 * a->M * (double)a->N * a->K;
   switch (a->epilogue) {
-    case SRK_EP_BF16: case SRK_EP_GELU: case SRK_EP_RES: case SRK_EP_LRELU: case SRK_EP_PS: case SRK_EP_IMG: case SRK_EP_RES_BF16:
+    case SRK_EP_BF16: case SRK_EP_GELU: case SRK_EP_RES: case SRK_EP_LRELU: case SRK_EP_PS: case SRK_EP_IMG: case SRK_EP_PS_IMG: case SRK_EP_RES_BF16:
       break;
     default:
       srk_set_error("gemm_ex: epilogue %d is not exposed", a->epilogue);
