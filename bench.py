@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W                 (N > 1 without WORLD_SIZE: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --config cfg2                                 (SwinIR-light x2 inference, 48x48 LR, bs 16: BASELINE cfg2)
-    python bench.py --config cfg4                                 (HAT x4 inference, 64x64 LR, bs 16: BASELINE cfg4)
+    python bench.py --config cfg4 | cfg5                          (HAT x4 / DAT x4 inference, 64x64 LR, bs 16: BASELINE cfg4 / cfg5)
 
 A step = forward + L1 loss + backward + (N>1: RCCL gradient all-reduce, overlapped) + clip 1.0 + AdamW on
 one batch of synthetic LR/HR patches already resident in HBM.  Prints ONE JSON line on rank 0.
@@ -142,6 +142,10 @@ INFER = {
                  workload="BASELINE cfg4: HAT-SRx4 (dim 180, 6x6 HAB + 6 OCAB, window 16, overlap 0.5, CAB) inference forward, 64x64 LR -> "
                           "256x256 HR, random-init weights",
                  kernel="linear-layer GEMMs (persistent LDS-DMA GEMMs + fused MLP kernel, csrc/gemm_stream.hip)"),
+    "cfg5": dict(metric="HR pixels/sec, DAT x4 inference, 64x64 LR, bs=16/GPU", batch=16, lr=64, scale=4, flop_per_image=136.64e9,
+                 workload="BASELINE cfg5: DAT x4 (dim 180, 6x6 blocks alternating 8x32|32x8 spatial and channel attention, SGFN expansion 4) "
+                          "inference forward (eval-mode BatchNorm), 64x64 LR -> 256x256 HR, random-init weights",
+                 kernel="linear-layer GEMMs (persistent LDS-DMA GEMMs, csrc/gemm_stream.hip)"),
 }
 
 
@@ -151,6 +155,9 @@ def build_infer_model(name, device):
     if name == "cfg2":
         m = T.SwinIR(upscale=2, in_chans=3, img_size=64, window_size=8, img_range=1.0, depths=[6] * 4, embed_dim=60,
                      num_heads=[6] * 4, mlp_ratio=2, upsampler="pixelshuffledirect")
+    elif name == "cfg5":      # official DAT x4 hyper-parameters (the reference only has a DAT-S-like __main__ demo: SURVEY 0)
+        m = T.DAT(upscale=4, in_chans=3, img_size=64, img_range=1.0, depth=[6] * 6, embed_dim=180, num_heads=[6] * 6, expansion_factor=4,
+                  resi_connection="1conv", split_size=[8, 32], upsampler="pixelshuffle")
     else:       # official HAT-SRx4 hyper-parameters (the reference repo never instantiates HAT: SURVEY 0)
         m = T.HAT(upscale=4, in_chans=3, img_size=64, window_size=16, compress_ratio=3, squeeze_factor=30, conv_scale=0.01,
                   overlap_ratio=0.5, img_range=1.0, depths=[6] * 6, embed_dim=180, num_heads=[6] * 6, mlp_ratio=2,
@@ -260,6 +267,11 @@ def cpu_baseline_infer(name, steps=3):
         cfg, batch = O.SwinIRConfig.light_x2(), 16
         sd = O.random_state_dict(cfg, 42, 1.0)
         fwd = lambda t: O.swinir_forward(sd, cfg, t)
+    elif name == "cfg5":
+        from oracle import dat_oracle as DO
+        cfg, batch = DO.DATConfig.sr_x4(), 2
+        sd = DO.random_state_dict(cfg, 42, 1.0)
+        fwd = lambda t: DO.dat_forward(sd, cfg, t)
     else:
         from oracle import hat_oracle as HO
         cfg, batch = HO.HATConfig.sr_x4(), 2
@@ -283,15 +295,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["cfg3", "cfg2", "cfg4"], default="cfg3",
-                    help="cfg3 (default): the headline train step; cfg2: SwinIR-light x2 inference; cfg4: HAT x4 inference")
+    ap.add_argument("--config", choices=["cfg3", "cfg2", "cfg4", "cfg5"], default="cfg3",
+                    help="cfg3 (default): the headline train step; cfg2: SwinIR-light x2 / cfg4: HAT x4 / cfg5: DAT x4 inference")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (BASELINE: 32 for cfg3, 16 for cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"cfg3": 20, "cfg2": 200, "cfg4": 10}[args.config]
+        args.steps = {"cfg3": 20, "cfg2": 200, "cfg4": 10, "cfg5": 10}[args.config]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])           # never returns
     if not torch.cuda.is_available():
