@@ -27,38 +27,70 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
 }
 
-// one thread = one pixel x 8 channels.  w: fp32 [C8*8][9] (zero rows for pad channels), scale / shift: fp32 [C8*8]
+// threadIdx.x = 8-channel group, threadIdx.y = pixel lane; the thread keeps its group's 72 weights + scale / shift in registers and walks
+// DW_ITER consecutive pixels of one image row with a sliding 3 x 3 register window (a first version re-read weights and all nine
+// neighbours per pixel: 350 us per launch at cfg5, 53 % of the DAT forward).
+// w: fp32 [C8*8][9] (zero rows for pad channels), scale / shift: fp32 [C8*8]
+constexpr int DW_ITER = 8;
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const bf16_t* __restrict__ mul, int ldm, bf16_t* __restrict__ out, int ldo, int B,
                                                         int H, int W, int C8, int act) {
-  const long long total = (long long)B * H * W * C8;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % C8);
-    const long long pix = i / C8;
-    const int xw = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  __shared__ float wsh[64 * 8 * 11];            // per channel: 9 taps, scale, shift (coalesced cooperative load, then registers)
+  const int nthr = blockDim.x * blockDim.y, lt = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = lt; i < C8 * 8 * 9; i += nthr) wsh[(i / 9) * 11 + i % 9] = w[i];
+  for (int i = lt; i < C8 * 8; i += nthr) {
+    wsh[i * 11 + 9] = scale[i];
+    wsh[i * 11 + 10] = shift[i];
+  }
+  __syncthreads();
+  const int cg = threadIdx.x;
+  float wr[9][8], sc[8], sh[8];
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int yy = y + dy;
-      if ((unsigned)yy >= (unsigned)H) continue;
+  for (int e = 0; e < 8; ++e) {
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = xw + dx;
-        if ((unsigned)xx >= (unsigned)W) continue;
-        float v[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (pix + (long long)dy * W + dx) * ldx + cg * 8), v);
-        const int tap = (dy + 1) * 3 + dx + 1;
+    for (int t = 0; t < 9; ++t) wr[t][e] = wsh[(cg * 8 + e) * 11 + t];
+    sc[e] = wsh[(cg * 8 + e) * 11 + 9];
+    sh[e] = wsh[(cg * 8 + e) * 11 + 10];
+  }
+  const long long npix = (long long)B * H * W;
+  const long long p0 = ((long long)blockIdx.x * blockDim.y + threadIdx.y) * DW_ITER;
+  if (p0 >= npix) return;
+  // the thread's DW_ITER pixels lie in one image row (W % DW_ITER == 0, checked by the launcher): a 3 x 3 register window slides along
+  // x, so every step loads one new column (3 x 16 bytes) instead of nine pieces
+  const int x0 = (int)(p0 % W);
+  const int y = (int)((p0 / W) % H);
+  float win[3][3][8];                       // [column slot][row dy + 1][channel]
+  auto load_col = [&](int slot, int xx) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[(cg * 8 + e) * 9 + tap], v[e], acc[e]);
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y + r - 1;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        unpack8(*reinterpret_cast<const uint4*>(x + (p0 + (long long)(r - 1) * W + (xx - x0)) * ldx + cg * 8), win[slot][r]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) win[slot][r][e] = 0.f;
       }
     }
+  };
+  load_col(0, x0 - 1);
+  load_col(1, x0);
+#pragma unroll
+  for (int it = 0; it < DW_ITER; ++it) {
+    const long long pix = p0 + it;
+    load_col((it + 2) % 3, x0 + it + 1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wr[r * 3 + dx][e], win[(it + dx) % 3][r][e], acc[e]);
     float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (mul) unpack8(*reinterpret_cast<const uint4*>(mul + pix * ldm + cg * 8), m);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = acc[e] * scale[cg * 8 + e] + shift[cg * 8 + e];
+      float v = acc[e] * sc[e] + sh[e];
       if (act == 1) v = gelu_f(v);
       acc[e] = v * m[e];
     }
@@ -234,41 +266,30 @@ __global__ __launch_bounds__(256) void chan_attn_finish_kernel(const float* __re
   }
 }
 
-// out[n][32 h + i] = sum_j A[b][h][i][j] v[n][32 h + j];  workgroup = 64 tokens of one sample, thread = (token, head) x 8 outputs
+// out[n][32 h + i] = sum_j A[b][h][i][j] v[n][32 h + j] on the matrix cores: one MFMA 16x16x32 per (16 tokens, head, 16 output
+// channels), K = the 32 (padded) channels of the head.  a operand = A rows as bf16 (the window-attention kernels round P the same
+// way), b operand = the tokens' v fragments straight from the qkv rows; D[i = 4 g + e][token = lane & 15].  One wave = 16 tokens.
 __global__ __launch_bounds__(256) void chan_apply_kernel(const bf16_t* __restrict__ qkv, int ldq, int CA, const float* __restrict__ A, int nH,
                                                          bf16_t* __restrict__ out, int ldo, int N) {
-  extern __shared__ float sm[];
-  float* As = sm;                      // [nH][32][33]
-  float* vs = sm + nH * 32 * 33;       // [64][CA + 1]
-  const int b = blockIdx.y, n0 = blockIdx.x * 64, tid = threadIdx.x;
-  for (int i = tid; i < nH * 1024; i += 256) As[(i >> 5) * 33 + (i & 31)] = A[(long long)b * nH * 1024 + i];
-  for (int i = tid; i < 64 * (CA / 4); i += 256) {
-    const int r = i / (CA / 4), c = (i - r * (CA / 4)) * 4;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    if (n0 + r < N) {
-      const uint2 u = *reinterpret_cast<const uint2*>(qkv + ((long long)b * N + n0 + r) * ldq + 2 * CA + c);
-      unpack_bf2(u.x, v0, v1); unpack_bf2(u.y, v2, v3);
-    }
-    float* d = vs + r * (CA + 1) + c;
-    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
-  }
-  __syncthreads();
-  const int groups = CA / 8;            // 8-channel output groups per token
-  for (int w = tid; w < 64 * groups; w += 256) {
-    const int r = w / groups, g8 = w - r * groups;
-    if (n0 + r >= N) continue;
-    const int h = g8 >> 2, i0 = (g8 & 3) * 8;
-    const float* vrow = vs + r * (CA + 1) + h * 32;
-    float o[8];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int n = blockIdx.x * 64 + wave * 16 + r16;
+  const bool ok = n < N;
+  const long long row = (long long)b * N + (ok ? n : 0);
+  for (int h = 0; h < nH; ++h) {
+    bf16x8_t vf = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) vf = *reinterpret_cast<const bf16x8_t*>(qkv + row * ldq + 2 * CA + h * 32 + 8 * g);
+    const float* Ah = A + ((long long)b * nH + h) * 1024;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float* arow = As + (h * 32 + i0 + e) * 33;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) s = fmaf(arow[j], vrow[j], s);
-      o[e] = s;
+    for (int mt = 0; mt < 2; ++mt) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Ah + (16 * mt + r16) * 32 + 8 * g);
+      const float4 a1 = *reinterpret_cast<const float4*>(Ah + (16 * mt + r16) * 32 + 8 * g + 4);
+      const uint2 lo = pack_bf4(a0.x, a0.y, a0.z, a0.w), hi = pack_bf4(a1.x, a1.y, a1.z, a1.w);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, u32x4{lo.x, lo.y, hi.x, hi.y});
+      const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, vf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      if (ok) *reinterpret_cast<uint2*>(out + row * ldo + h * 32 + 16 * mt + 4 * g) = pack_bf4(d[0], d[1], d[2], d[3]);
     }
-    *reinterpret_cast<uint4*>(out + ((long long)b * N + n0 + r) * ldo + g8 * 8) = pack8(o);
   }
 }
 
@@ -286,8 +307,14 @@ int srk_dwconv3x3(const uint16_t* x, int ldx, const float* w, const float* scale
   SRK_REQUIRE(x && w && scale && shift && out, SRK_E_NULL, "dwconv3x3: null pointer");
   SRK_REQUIRE(B > 0 && H > 0 && W > 0 && C8 > 0 && ldx >= 8 * C8 && ldo >= 8 * C8 && ldx % 8 == 0 && ldo % 8 == 0 && (mul == nullptr || ldm % 8 == 0),
               SRK_E_SHAPE, "dwconv3x3: bad shape / strides (16-byte pieces)");
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long long)B * H * W * C8)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, scale, shift, mul,
-                     ldm, out, ldo, B, H, W, C8, act);
+  SRK_REQUIRE(C8 <= 64, SRK_E_SHAPE, "dwconv3x3: at most 512 channels (got %d)", 8 * C8);
+  SRK_REQUIRE(W % DW_ITER == 0, SRK_E_UNSUPPORTED, "dwconv3x3: the image width must be a multiple of %d (got %d)", DW_ITER, W);
+  const int py = 256 / C8 < 1 ? 1 : 256 / C8;                          // pixel lanes per workgroup
+  const long long npix = (long long)B * H * W;
+  const long long blocks = (npix + (long long)py * DW_ITER - 1) / ((long long)py * DW_ITER);
+  SRK_REQUIRE(blocks < (1LL << 31), SRK_E_SHAPE, "dwconv3x3: too many pixels");
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(C8, py), 0, (hipStream_t)stream, x, ldx, w, scale, shift, mul, ldm, out, ldo, B,
+                     H, W, C8, act);
   return srk_check_launch("dwconv3x3");
 }
 
@@ -296,7 +323,8 @@ int srk_rowln_bf16(const uint16_t* x, int ldx, const float* gamma, const float* 
   SRK_REQUIRE(x && gamma && beta && out, SRK_E_NULL, "rowln: null pointer");
   SRK_REQUIRE(rows > 0 && C > 0 && C <= 512 && CP_out >= C && CP_out <= 512 && CP_out % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, SRK_E_SHAPE,
               "rowln: C=%d (<= 512) CP_out=%d", C, CP_out);
-  hipLaunchKernelGGL(rowln_bf16_kernel, dim3(grid_for(rows, 4, 16384)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, out, ldo,
+  // few, long-lived workgroups: every thread loads its 16 gamma / beta values once and then walks many rows
+  hipLaunchKernelGGL(rowln_bf16_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, out, ldo,
                      (long long)rows, C, CP_out);
   return srk_check_launch("rowln_bf16");
 }
@@ -305,7 +333,7 @@ int srk_spatial_gate(const uint16_t* x, int ldx, const float* W0, const float* b
                      int CP, srk_stream_t stream) {
   SRK_REQUIRE(x && W0 && b0 && w3 && gate, SRK_E_NULL, "spatial_gate: null pointer");
   SRK_REQUIRE(rows > 0 && S > 0 && S <= 16 && ldx % 4 == 0, SRK_E_SHAPE, "spatial_gate: S=%d (<= 16)", S);
-  const int grid = grid_for(rows, 16, 8192);
+  const int grid = grid_for(rows, 16, 1024);
 #define SG_CASE(NV)                                                                                                                     \
   if (CP == 64 * NV) {                                                                                                                  \
     hipLaunchKernelGGL(spatial_gate_kernel<NV>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, W0, b0, w3, b3, S, gate, (long long)rows); \
@@ -335,23 +363,14 @@ int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float*
                               int N, int num_heads, int head_dim, srk_stream_t stream) {
   SRK_REQUIRE(qkv && temperature && workspace && out, SRK_E_NULL, "channel_attention: null pointer");
   SRK_REQUIRE(B > 0 && B < 65536 && N > 0 && num_heads > 0 && num_heads <= 8 && head_dim > 0 && head_dim <= 32 && CA == num_heads * 32 &&
-                  ldq >= 3 * CA && ldq % 4 == 0 && ldo >= CA && ldo % 8 == 0,
+                  ldq >= 3 * CA && ldq % 8 == 0 && ldo >= CA && ldo % 4 == 0,
               SRK_E_SHAPE, "channel_attention: bad shape B=%d N=%d heads=%d d=%d CA=%d", B, N, num_heads, head_dim, CA);
   const int nchunk = (N + GCH - 1) / GCH;
   float* partial = static_cast<float*>(workspace);
   float* A = partial + (size_t)B * num_heads * nchunk * GSZ;
   hipLaunchKernelGGL(chan_gram_partial_kernel, dim3(nchunk, num_heads, B), dim3(256), 0, (hipStream_t)stream, qkv, ldq, CA, partial, N);
   hipLaunchKernelGGL(chan_attn_finish_kernel, dim3(num_heads, B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, head_dim, temperature, A);
-  const size_t lds = ((size_t)num_heads * 32 * 33 + 64 * (size_t)(CA + 1)) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      srk_set_error("channel_attention: cannot reserve LDS");
-      return SRK_E_LAUNCH;
-    }
-    configured = true;
-  }
-  hipLaunchKernelGGL(chan_apply_kernel, dim3((N + 63) / 64, B), dim3(256), lds, (hipStream_t)stream, qkv, ldq, CA, A, num_heads, out, ldo, N);
+  hipLaunchKernelGGL(chan_apply_kernel, dim3((N + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, qkv, ldq, CA, A, num_heads, out, ldo, N);
   return srk_check_launch("channel_attention");
 }
 
