@@ -183,7 +183,7 @@ int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float
  * K = 9 * CinP tap-major).  W bf16 [N][K].  N % 64 == 0 (N == 16 for the image head), K % 64 == 0. */
 enum { SRK_LD_ROWS = 0, SRK_LD_CONV3 = 1 };
 enum { SRK_EP_BF16 = 0,       /* outb = bf16(v + bias) */
-       SRK_EP_GELU = 3,       /* outb = bf16(u), outb2 = bf16(gelu(u)), u = v + bias */
+       SRK_EP_GELU = 3,       /* outb2 = bf16(gelu(u)), u = v + bias; outb = bf16(u) if not null (kept for a backward pass) */
        SRK_EP_RES = 4,        /* outf = res + v + bias (fp32) [+ outb bf16 copy] [+ LayerNorm of the new row -> xn_out, N == 64/128/192] */
        SRK_EP_LRELU = 6,      /* outb = bf16(leaky_relu(v + bias, scale)) */
        SRK_EP_PS = 7,         /* conv + PixelShuffle(r): W rows permuted to (i*r + j)*Cs + c; store is the shuffled NHWC tensor */

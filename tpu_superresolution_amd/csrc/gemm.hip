@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         const float4 rv = *reinterpret_cast<const float4*>(p.res + t * p.ldo + n);
         *reinterpret_cast<float4*>(p.outf + t * p.ldo + n) = make_float4(rv.x + v0, rv.y + v1, rv.z + v2, rv.w + v3);
       } else if constexpr (EP == EP_GELU) {
-        *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v0, v1, v2, v3);
+        if (p.outb) *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v0, v1, v2, v3);
         *reinterpret_cast<uint2*>(p.outb2 + (long long)m * p.ldo + n) =
             gelu_pack4(v0, v1, v2, v3);
       } else if constexpr (EP == EP_RES) {

@@ -218,7 +218,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
         for (int c = 0; c < NC; ++c) {
           const int n = n0 + 64 * c + 4 * j16;
           if (n >= p.N) continue;
-          *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
+          if (p.outb) *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);   // u: training only
           *reinterpret_cast<uint2*>(p.outb2 + (long long)m * p.ldo + n) =
               gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w);
         }

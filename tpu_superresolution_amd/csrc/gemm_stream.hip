@@ -390,10 +390,12 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
       for (int c = 0; c < NC; ++c) {
         const long long o = (long long)m * p.ldo + n0 + 64 * c + 4 * j16;
         const uint2 pu = pack_bf4(v[c].x, v[c].y, v[c].z, v[c].w);
-        if constexpr (SRK_NT_STORE_U != 0)   // u is next read by the backward pass: keep it out of the caches
-          __builtin_nontemporal_store(srk_u2{pu.x, pu.y}, reinterpret_cast<srk_u2*>(p.outb + o));
-        else
-          st_u2(p.outb + o, pu);
+        if (p.outb) {                          // the pre-activation is only kept for a backward pass (inference callers pass null)
+          if constexpr (SRK_NT_STORE_U != 0)   // u is next read by the backward pass: keep it out of the caches
+            __builtin_nontemporal_store(srk_u2{pu.x, pu.y}, reinterpret_cast<srk_u2*>(p.outb + o));
+          else
+            st_u2(p.outb + o, pu);
+        }
         st_u2(p.outb2 + o, gelu_pack4(v[c].x, v[c].y, v[c].z, v[c].w));
       }
     } else if constexpr (EP == EP_DGELU) {

@@ -752,7 +752,7 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
       {  // Mlp (:25-28) + second residual (:277): fc1 + GELU and fc2 + residual, as one kernel where it applies
         GemmParams g1 = {};   // fc1 + GELU
         g1.A = c.at<bf16_t>(ba.xn2); g1.lda = CP; g1.Wt = c.packed + bw.Wfc1; g1.M = T; g1.N = HP; g1.K = CP;
-        g1.bias = c.side + bw.bfc1; g1.outb = c.at<bf16_t>(ba.u); g1.outb2 = c.at<bf16_t>(ba.h); g1.ldo = HP; g1.flops = fl_mlp;
+        g1.bias = c.side + bw.bfc1; g1.outb = w.training ? c.at<bf16_t>(ba.u) : nullptr; g1.outb2 = c.at<bf16_t>(ba.h); g1.ldo = HP; g1.flops = fl_mlp;
         g1.bytes = (double)T * (2.0 * C + 4.0 * p->HID) + 2.0 * C * p->HID;           // xn2 in; u, h out
         GemmParams g = {};    // fc2 + residual
         g.A = c.at<bf16_t>(ba.h); g.lda = HP; g.Wt = c.packed + bw.Wfc2; g.M = T; g.N = CP; g.K = HP;

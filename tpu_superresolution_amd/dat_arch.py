@@ -415,7 +415,7 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
     gate_ws = torch.empty(max(1, int(L.srk_channel_gate_workspace(B, HW, CAmax))), dtype=torch.uint8, device=dev)
     ca_ws = torch.empty(max(1, int(L.srk_channel_attention_workspace(B, HW, max(m.heads)))), dtype=torch.uint8, device=dev)
     xn2 = torch.empty(T, CP, **b16)
-    hu, hh = torch.empty(T, 2 * HPh, **b16), torch.empty(T, 2 * HPh, **b16)
+    hh = torch.empty(T, 2 * HPh, **b16)
     x2n, gated = torch.empty(T, HPh, **b16), torch.empty(T, HPh, **b16)
     xb = torch.empty(T, CP, **b16)
     stat_a, stat_b = torch.empty(T, **f32), torch.empty(T, **f32)
@@ -455,7 +455,7 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, comb, P[pre + "Wproj"], T, CP, CA, lda=CA, bias=P[pre + "bproj"], res=cur, outf=x1,
                   xn=dict(out=xn2, mean=stat_a, rstd=stat_b, gamma=blk.norm2.weight, beta=blk.norm2.bias, C=C_))
             # SGFN (:74-90): fc1 + GELU, x1 * DWconv(LN(x2)), fc2 + residual
-            _gemm(st, _lib.LD_ROWS, _lib.EP_GELU, xn2, P[pre + "W1"], T, 2 * HPh, CP, lda=CP, bias=P[pre + "b1"], outb=hu, outb2=hh)
+            _gemm(st, _lib.LD_ROWS, _lib.EP_GELU, xn2, P[pre + "W1"], T, 2 * HPh, CP, lda=CP, bias=P[pre + "b1"], outb2=hh)
             check(L.srk_rowln_bf16(hh.data_ptr() + HPh * 2, 2 * HPh, blk.ffn.sg.norm.weight.data_ptr(), blk.ffn.sg.norm.bias.data_ptr(), x2n.data_ptr(),
                                    HPh, T, half, HPh, st))
             check(L.srk_dwconv3x3(x2n.data_ptr(), HPh, P[pre + "sg_w"].data_ptr(), P[pre + "sg_s"].data_ptr(), P[pre + "sg_t"].data_ptr(), hh.data_ptr(),

@@ -489,12 +489,12 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
     # scratch shared by all blocks
     qkv = torch.empty(T, 3 * max(h * 32 for h in m.heads), **b16)
     ao = torch.empty(T, max(h * 32 for h in m.heads), **b16)
-    c1u, c1 = torch.empty(T, 64, **b16), torch.empty(T, 64, **b16)
+    c1 = torch.empty(T, 64, **b16)
     c2 = torch.empty(T, CP, **b16)
     gate = torch.empty(B, CP, **f32)
     gate_ws = torch.empty(max(1, int(L.srk_channel_gate_workspace(B, HW, CP))), dtype=torch.uint8, device=dev)
     xn2 = torch.empty(T, CP, **b16)
-    hu, hh = torch.empty(T, HP, **b16), torch.empty(T, HP, **b16)
+    hh = torch.empty(T, HP, **b16)
     xb = torch.empty(T, CP, **b16)
     stat_a, stat_b = torch.empty(T, **f32), torch.empty(T, **f32)
     fused_mlp_ok = (CP == 192 and HP == 384 and T % 64 == 0 and T >= 64 * torch.cuda.get_device_properties(dev).multi_processor_count)
@@ -506,7 +506,7 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
                                       P[pre + "b2"].data_ptr(), x_res.data_ptr(), out.data_ptr(), _ptr(out_b), None, None, None, None, None,
                                       0, T, st))
         else:
-            _gemm(st, _lib.LD_ROWS, _lib.EP_GELU, xn_in, P[pre + "W1"], T, HP, CP, lda=CP, bias=P[pre + "b1"], outb=hu, outb2=hh)
+            _gemm(st, _lib.LD_ROWS, _lib.EP_GELU, xn_in, P[pre + "W1"], T, HP, CP, lda=CP, bias=P[pre + "b1"], outb2=hh)
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, hh, P[pre + "W2"], T, CP, HP, lda=HP, bias=P[pre + "b2"], res=x_res, outf=out, outb=out_b)
 
     for li, layer in enumerate(m.layers):
@@ -525,7 +525,7 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
             x1 = torch.empty(T, CP, **f32)
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, ao, P[pre + "Wproj"], T, CP, CA, lda=CA, bias=P[pre + "bproj"], res=cur, outf=x1)
             # conv branch on the un-shifted normed features (:294-295): conv3x3 + GELU, conv3x3, channel-attention gate
-            _gemm(st, _lib.LD_CONV3, _lib.EP_GELU, xn1, P[pre + "Wc0"], T, 64, 9 * CP, conv=(B, H, W, CP), bias=P[pre + "bc0"], outb=c1u, outb2=c1)
+            _gemm(st, _lib.LD_CONV3, _lib.EP_GELU, xn1, P[pre + "Wc0"], T, 64, 9 * CP, conv=(B, H, W, CP), bias=P[pre + "bc0"], outb2=c1)
             _gemm(st, _lib.LD_CONV3, _lib.EP_BF16, c1, P[pre + "Wc2"], T, CP, 9 * 64, conv=(B, H, W, 64), bias=P[pre + "bc2"], outb=c2)
             S = P[pre + "ca_w1"].shape[0]
             check(L.srk_channel_gate(c2.data_ptr(), gate_ws.data_ptr(), P[pre + "ca_w1"].data_ptr(), P[pre + "ca_b1"].data_ptr(),
