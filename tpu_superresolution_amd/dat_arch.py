@@ -419,7 +419,14 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
     x2n, gated = torch.empty(T, HPh, **b16), torch.empty(T, HPh, **b16)
     xb = torch.empty(T, CP, **b16)
     stat_a, stat_b = torch.empty(T, **f32), torch.empty(T, **f32)
+    stat_c, stat_d = torch.empty(T, **f32), torch.empty(T, **f32)
+    ln_fusable = CP in (64, 128, 192)          # the LayerNorm that consumes a freshly written row rides in the producer's epilogue
+    xn_a, xn_b = torch.empty(T, CP, **b16), torch.empty(T, CP, **b16)
 
+    def next_norm(norm, dst):
+        return dict(out=dst, mean=stat_c, rstd=stat_d, gamma=norm.weight, beta=norm.bias, C=C_) if ln_fusable else None
+
+    xn1 = None            # norm1 of the upcoming block when the previous kernel already produced it in its epilogue
     for li, layer in enumerate(m.layers):
         nH = m.heads[li]
         CA, hb = nH * 32, nH // 2
@@ -428,7 +435,8 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
         nblk = len(layer.blocks)
         for bi, blk in enumerate(layer.blocks):
             pre = f"{li}.{bi}."
-            xn1, _, _, _ = ops.layernorm_fwd(cur, blk.norm1.weight, blk.norm1.bias, C_)
+            if xn1 is None:
+                xn1, _, _, _ = ops.layernorm_fwd(cur, blk.norm1.weight, blk.norm1.bias, C_)
             _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, xn1, P[pre + "Wqkv"], T, 3 * CA, CP, lda=CP, bias=P[pre + "bqkv"], outb=qkv, ldo=3 * CA)
             # DW-conv branch on v (:418, :508): conv + BatchNorm + GELU
             check(L.srk_dwconv3x3(qkv.data_ptr() + 2 * CA * 2, 3 * CA, P[pre + "dw_w"].data_ptr(), P[pre + "dw_s"].data_ptr(), P[pre + "dw_t"].data_ptr(),
@@ -461,14 +469,21 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
             check(L.srk_dwconv3x3(x2n.data_ptr(), HPh, P[pre + "sg_w"].data_ptr(), P[pre + "sg_s"].data_ptr(), P[pre + "sg_t"].data_ptr(), hh.data_ptr(),
                                   2 * HPh, gated.data_ptr(), HPh, B, H, W, HPh // 8, 0, st))
             nxt = torch.empty(T, CP, **f32)
+            last = bi == nblk - 1
+            dst = xn_a if xn1 is not xn_a else xn_b
+            nn_ = None if last else next_norm(layer.blocks[bi + 1].norm1, dst)
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, gated, P[pre + "W2"], T, CP, HPh, lda=HPh, bias=P[pre + "b2"], res=x1, outf=nxt,
-                  outb=xb if bi == nblk - 1 else None)
+                  outb=xb if last else None, xn=nn_)
             cur = nxt
+            xn1 = dst if nn_ is not None else None
         nxt = torch.empty(T, CP, **f32)                               # ResidualGroup :653-657: conv + residual
-        _gemm(st, _lib.LD_CONV3, _lib.EP_RES, xb, P[f"{li}.Wconv"], T, CP, 9 * CP, conv=(B, H, W, CP), bias=P[f"{li}.bconv"], res=layer_in, outf=nxt)
+        nn_ = next_norm(m.layers[li + 1].blocks[0].norm1 if li + 1 < len(m.layers) else m.norm, xn_a)        # next norm1 / the final norm :750
+        _gemm(st, _lib.LD_CONV3, _lib.EP_RES, xb, P[f"{li}.Wconv"], T, CP, 9 * CP, conv=(B, H, W, CP), bias=P[f"{li}.bconv"], res=layer_in, outf=nxt,
+              xn=nn_)
         cur = nxt
+        xn1 = xn_a if nn_ is not None else None
 
-    xnf, _, _, _ = ops.layernorm_fwd(cur, m.norm.weight, m.norm.bias, C_)
+    xnf = xn1 if xn1 is not None else ops.layernorm_fwd(cur, m.norm.weight, m.norm.bias, C_)[0]
     fb = torch.empty(T, CP, **b16)
     _gemm(st, _lib.LD_CONV3, _lib.EP_RES_BF16, xnf, P["Wcab"], T, CP, 9 * CP, conv=(B, H, W, CP), bias=P["bcab"], res=f0, outb=fb)
     y = torch.empty(B, Cin, H * s, W * s, **f32)

@@ -499,24 +499,35 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
     stat_a, stat_b = torch.empty(T, **f32), torch.empty(T, **f32)
     fused_mlp_ok = (CP == 192 and HP == 384 and T % 64 == 0 and T >= 64 * torch.cuda.get_device_properties(dev).multi_processor_count)
 
-    def mlp(pre, xn_in, x_res, out, out_b=None):
-        """out = x_res + fc2(gelu(fc1(xn_in)))   (Mlp.forward :86-92 + the residual add)"""
+    ln_fusable = CP in (64, 128, 192)          # the LayerNorm that consumes a freshly written row rides in the producer's epilogue
+    xn_a, xn_b = torch.empty(T, CP, **b16), torch.empty(T, CP, **b16)
+
+    def next_norm(norm, dst):
+        return dict(out=dst, mean=stat_a, rstd=stat_b, gamma=norm.weight, beta=norm.bias, C=C_) if (ln_fusable and norm is not None) else None
+
+    def mlp(pre, xn_in, x_res, out, out_b=None, nn_=None):
+        """out = x_res + fc2(gelu(fc1(xn_in)))   (Mlp.forward :86-92 + the residual add) [+ the next LayerNorm of the new rows]"""
         if fused_mlp_ok:
+            args = (None, None, None, None, None, 0) if nn_ is None else (nn_["out"].data_ptr(), nn_["mean"].data_ptr(), nn_["rstd"].data_ptr(),
+                                                                       nn_["gamma"].data_ptr(), nn_["beta"].data_ptr(), nn_["C"])
             check(L.srk_mlp_fused_fwd(xn_in.data_ptr(), P[pre + "W1"].data_ptr(), P[pre + "b1"].data_ptr(), P[pre + "W2"].data_ptr(),
-                                      P[pre + "b2"].data_ptr(), x_res.data_ptr(), out.data_ptr(), _ptr(out_b), None, None, None, None, None,
-                                      0, T, st))
+                                      P[pre + "b2"].data_ptr(), x_res.data_ptr(), out.data_ptr(), _ptr(out_b), *args, T, st))
         else:
             _gemm(st, _lib.LD_ROWS, _lib.EP_GELU, xn_in, P[pre + "W1"], T, HP, CP, lda=CP, bias=P[pre + "b1"], outb2=hh)
-            _gemm(st, _lib.LD_ROWS, _lib.EP_RES, hh, P[pre + "W2"], T, CP, HP, lda=HP, bias=P[pre + "b2"], res=x_res, outf=out, outb=out_b)
+            _gemm(st, _lib.LD_ROWS, _lib.EP_RES, hh, P[pre + "W2"], T, CP, HP, lda=HP, bias=P[pre + "b2"], res=x_res, outf=out, outb=out_b, xn=nn_)
 
+    xn1 = None            # norm1 of the upcoming block when the previous kernel already produced it in its epilogue
     for li, layer in enumerate(m.layers):
         nH = m.heads[li]
         CA = nH * 32
         scale = float(m.qk_scale or (C_ // nH) ** -0.5)
         layer_in = cur
-        for bi, blk in enumerate(layer.residual_group.blocks):
+        blocks = list(layer.residual_group.blocks)
+        oc = layer.residual_group.overlap_attn
+        for bi, blk in enumerate(blocks):
             pre = f"{li}.{bi}."
-            xn1, _, _, _ = ops.layernorm_fwd(cur, blk.norm1.weight, blk.norm1.bias, C_)                          # norm1 :290
+            if xn1 is None:
+                xn1, _, _, _ = ops.layernorm_fwd(cur, blk.norm1.weight, blk.norm1.bias, C_)                      # norm1 :290
             _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, xn1, P[pre + "Wqkv"], T, 3 * CA, CP, lda=CP, bias=P[pre + "bqkv"], outb=qkv, ldo=3 * CA)
             sh = blk.shift_size
             tab = blk.attn.relative_position_bias_table        # the kernel indexes the table itself (rpi in closed form)
@@ -534,11 +545,15 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
             check(L.srk_cab_add_ln(x1.data_ptr(), c2.data_ptr(), gate.data_ptr(), blk.norm2.weight.data_ptr(), blk.norm2.bias.data_ptr(),
                                    xn2.data_ptr(), T, HW, C_, CP, st))                                            # :322-323
             nxt = torch.empty(T, CP, **f32)
-            mlp(pre, xn2, x1, nxt)
+            following = blocks[bi + 1].norm1 if bi + 1 < len(blocks) else oc.norm1
+            dst = xn_a if xn1 is not xn_a else xn_b                       # this block's xn1 is still read by nobody, but keep them apart
+            nn_ = next_norm(following, dst)
+            mlp(pre, xn2, x1, nxt, nn_=nn_)
             cur = nxt
-        oc = layer.residual_group.overlap_attn                                                                    # OCAB :389-439
-        pre = f"{li}.oca."
-        xn1, _, _, _ = ops.layernorm_fwd(cur, oc.norm1.weight, oc.norm1.bias, C_)
+            xn1 = dst if nn_ is not None else None
+        pre = f"{li}.oca."                                                                                        # OCAB :389-439
+        if xn1 is None:
+            xn1, _, _, _ = ops.layernorm_fwd(cur, oc.norm1.weight, oc.norm1.bias, C_)
         _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, xn1, P[pre + "Wqkv"], T, 3 * CA, CP, lda=CP, bias=P[pre + "bqkv"], outb=qkv, ldo=3 * CA)
         tab = oc.relative_position_bias_table
         check(L.srk_win256_attention_fwd(qkv.data_ptr(), 3 * CA, CA, tab.data_ptr(), tab.shape[0], ao.data_ptr(), CA, B, H, W, ws, ws, 0, 0, nH,
@@ -549,10 +564,14 @@ def _hat_forward(m: HAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
         x2 = torch.empty(T, CP, **f32)
         mlp(pre, xn2, x1, x2, out_b=xb)
         nxt = torch.empty(T, CP, **f32)                                                                          # RHAG :619: conv + residual
-        _gemm(st, _lib.LD_CONV3, _lib.EP_RES, xb, P[f"{li}.Wconv"], T, CP, 9 * CP, conv=(B, H, W, CP), bias=P[f"{li}.bconv"], res=layer_in, outf=nxt)
+        following = m.layers[li + 1].residual_group.blocks[0].norm1 if li + 1 < len(m.layers) else m.norm      # next norm1 / final norm :958
+        nn_ = next_norm(following, xn_a)
+        _gemm(st, _lib.LD_CONV3, _lib.EP_RES, xb, P[f"{li}.Wconv"], T, CP, 9 * CP, conv=(B, H, W, CP), bias=P[f"{li}.bconv"], res=layer_in, outf=nxt,
+              xn=nn_)
         cur = nxt
+        xn1 = xn_a if nn_ is not None else None
 
-    xnf, _, _, _ = ops.layernorm_fwd(cur, m.norm.weight, m.norm.bias, C_)                                        # norm :958
+    xnf = xn1 if xn1 is not None else ops.layernorm_fwd(cur, m.norm.weight, m.norm.bias, C_)[0]                  # norm :958
     fb = torch.empty(T, CP, **b16)
     _gemm(st, _lib.LD_CONV3, _lib.EP_RES_BF16, xnf, P["Wcab"], T, CP, 9 * CP, conv=(B, H, W, CP), bias=P["bcab"], res=f0, outb=fb)
     t1 = torch.empty(T, 64, **b16)
