@@ -80,7 +80,9 @@ class _WindowAttention(torch.autograd.Function):
             s = (s.view(B_ // nW, nW, nH, 64, 64) + mask[None, :, None]).view(B_, nH, 64, 64)
         p = torch.softmax(s, dim=-1)
         ctx.save_for_backward(q, k, v, p)
-        return _bf(_bf(p) @ v)
+        # forward kernels feed the UNNORMALISED numerators exp(s - max) to the P.V MFMA as bf16 and scale the outputs
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        return _bf((_bf(e) @ v) / e.sum(dim=-1, keepdim=True))
 
     @staticmethod
     def backward(ctx, do):

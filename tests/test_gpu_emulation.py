@@ -44,6 +44,14 @@ def test_forward_and_gradients_match_bf16_emulation(tag, drop):
         t = torch.rand(x.shape[0], x.shape[1], 16 * cfg.upscale, 16 * cfg.upscale, generator=torch.Generator().manual_seed(5))
     ds = _drop_factors(sum(cfg.depths), x.shape[0], 0.3, 3) if drop else None
     loss_e, out_e, grads_e = E.loss_and_grads_emul(sd, cfg, x, t, drop_keep=ds)
+    # d(L1)/d(out) = sign(out - t) / N: a pixel whose output lands within the bf16 noise of its target can flip sign between the
+    # two implementations, and ONE flip among ~1e3 outputs is a 6 % relative change of every gradient tensor.  Move such targets
+    # away from the output (the comparison is about the backward algebra, not about ties of the loss).
+    margin = 2.0 * (1e-2 if cfg.resi_connection == "3conv" else FWD_TOL) * float(out_e.abs().max())     # twice the forward tolerance
+    close = (out_e - t).abs() < margin
+    if bool(close.any()):
+        t = torch.where(close, out_e + torch.where(t >= out_e, 5.0 * margin, -5.0 * margin), t)
+        loss_e, out_e, grads_e = E.loss_and_grads_emul(sd, cfg, x, t, drop_keep=ds)
 
     m = build(cfg, sd, train=True, drop_path_rate=0.3 if drop else 0.0)
     out = m(x.cuda(), drop_scale=None if ds is None else ds.cuda())

@@ -197,36 +197,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
           for (int e = 0; e < 4; ++e)
             if (win_region_label(geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
       }
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
-      mx = xmax4(mx);
-      float sum = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s[jt][e] = __expf(s[jt][e] - mx);
-          sum += s[jt][e];
-        }
-      const float inv = 1.0f / xsum4(sum);
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[jt][e] *= inv;
     }
+    bf16x8_t pf[2];
+    const float inv = softmax_numerators(s, pf);      // unnormalised exp(s - max) as bf16; the outputs are scaled (as attn_fused.hip)
     f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      const uint2 lo = pack_bf4(s[2 * ss][0], s[2 * ss][1], s[2 * ss][2], s[2 * ss][3]);
-      const uint2 hi = pack_bf4(s[2 * ss + 1][0], s[2 * ss + 1][1], s[2 * ss + 1][2], s[2 * ss + 1][3]);
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_acc(Vs, TS, 32 * ss, 16 * dt, lane), pf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_acc(Vs, TS, 32 * ss, 16 * dt, lane), pf[ss], o[dt], 0, 0, 0);
     }
+    o[0] *= inv;
+    o[1] *= inv;
     // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]
     // exchange the dt = 0 quad of the odd 16-lane rows with the dt = 1 quad of the even ones (v_permlane16_swap): every lane
     // then owns 8 consecutive d -> one 16-byte store, 64-byte runs per row (see the backward kernel)
@@ -323,15 +305,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
       mx = xmax4(mx);
-      float sum = 0.f;
+      constexpr float L2E = 1.4426950408889634f;      // exp(x - m) = exp2(x log2e - m log2e), as softmax_numerators
+      const float mxl = mx * L2E;
+      f32x4_t a4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 4; ++jt) {
+        const f32x4_t t = s[jt] * L2E - mxl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s[jt][e] = __expf(s[jt][e] - mx);
-          sum += s[jt][e];
-        }
-      const float inv = 1.0f / xsum4(sum);
+        for (int e = 0; e < 4; ++e) s[jt][e] = __builtin_amdgcn_exp2f(t[e]);
+        a4 += s[jt];
+      }
+      const float inv = __builtin_amdgcn_rcpf(xsum4((a4[0] + a4[1]) + (a4[2] + a4[3])));
       float dl = 0.f;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)

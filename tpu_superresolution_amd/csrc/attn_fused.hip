@@ -36,13 +36,29 @@
 #endif
 typedef unsigned srk_u4 __attribute__((ext_vector_type(4)));
 
+#ifdef SRK_PROBE_ATTN
+// developer instrumentation (never in the shipped build): s_memrealtime (100 MHz) at the phase boundaries of workgroup 0
+__device__ unsigned long long g_attn_probe[8 * 16 * 8];
+#define ATTN_MARK(k) do { if (blockIdx.x == 0 && lane == 0 && t < 16) g_attn_probe[(wave * 16 + t) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int srk_debug_attn_probe(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_probe), sizeof(g_attn_probe)); }
+__device__ unsigned long long g_attn_unit_probe[8 * 3 * 8];
+#define UNIT_MARK(m) do { if (blockIdx.x == 0 && lane == 0 && t == 3) g_attn_unit_probe[(wave * 3 + k) * 8 + (m)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int srk_debug_attn_unit_probe(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_unit_probe), sizeof(g_attn_unit_probe)); }
+#else
+#define ATTN_MARK(k) do {} while (0)
+#define UNIT_MARK(m) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int FT = 40;                 // LDS row stride (elements) of a [64][32] bf16 head tile (as attn.hip TS)
 constexpr int F_K = 192, F_CA = 192, F_NH = 6;
 constexpr int F_SLOT = 64 * F_K * 2;   // 24576 B: one window of xn1 / the ao tile
 constexpr int F_TILE = 64 * FT;        // elements per head tile
-constexpr int F_LDS = 2 * F_SLOT + 18 * F_TILE * 2 + 3 * F_CA * 4;    // ring + head tiles + projection bias (fp32)
+constexpr int F_TAB = 225;             // (2 ws - 1)^2 relative-position offsets
+constexpr int F_OFF_PBIAS = 2 * F_SLOT + 18 * F_TILE * 2;
+constexpr int F_OFF_TAB = F_OFF_PBIAS + 3 * F_CA * 4;
+constexpr int F_LDS = F_OFF_TAB + F_NH * F_TAB * 4;    // ring + head tiles + projection bias (fp32) + rel-pos bias table [6][225]
 
 struct FusedParams {
   const bf16_t* xn;     // [B_*64][lda] window-order rows
@@ -65,7 +81,7 @@ __device__ __forceinline__ bf16x8_t f_cat4(bf16x4_t lo, bf16x4_t hi) {
 template <int NF, bool LOADER>
 __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* smem, int wave, int lane, long long nwin) {
   bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + 2 * F_SLOT);       // [which][head][64][FT]
-  const float* pbias = reinterpret_cast<const float*>(smem + 2 * F_SLOT + 18 * F_TILE * 2);
+  const float* pbias = reinterpret_cast<const float*>(smem + F_OFF_PBIAS);
   const unsigned smem_base = (unsigned)(size_t)smem;
   const int r16 = lane & 15, g = lane >> 4;
   const int f0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);          // first fragment of this wave
@@ -95,29 +111,24 @@ __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* 
       for (int i = 0; i < 24; ++i) srk_glds16<SRK_NT_ATTN != 0>(base + off[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
     }
   };
-  auto load_bias = [&](f32x4_t (&b)[4], int u) {      // rel-pos bias rows of unit u = 4 h + it, this lane's 16 values
-    const float* bp = p.biasd + (u >> 2) * 4096 + (16 * (u & 3) + r16) * 64 + 4 * g;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * jt);
-      b[jt] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
-    }
-  };
-
+  // rel-pos bias: this lane's query i = 16 it + r16 is the same in all three units of the wave (it = wave & 3); key
+  // j = 16 jt + 4 g + e -> table index (yi - yj + 7) 15 + (xi - xj + 7) = lane_idx - 30 jt - e   (network_swinir.py:89-103)
+  const int it = wave & 3, hw = wave >> 2;
+  const float* tabl = reinterpret_cast<const float*>(smem + F_OFF_TAB) +
+                      ((2 * it + (r16 >> 3)) - (g >> 1) + 7) * 15 + ((r16 & 7) - 4 * (g & 1) + 7) - 93;
   if constexpr (LOADER) issue(0);
   for (long long t = 0; t < nwin; ++t) {
     const long long b_ = blockIdx.x + t * gridDim.x;
     const unsigned char* As = smem + (t & 1) * F_SLOT;
-    f32x4_t bnext[4];
+    ATTN_MARK(0);
     if constexpr (LOADER) {
       srk_wait_vmcnt<0>();                      // this wave's DMAs of window t (and nothing else) have landed
       srk_lds_barrier();                        // Ba
       if (t + 1 < nwin) issue(t + 1);           // into slot (t+1)&1: the ao tile it held (window t-1) was stored before Ba(t)
-      load_bias(bnext, wave);
     } else {
-      load_bias(bnext, wave);                   // consumed after the projection
       srk_lds_barrier();                        // Ba: xn1 rows of window t are in LDS; head tiles are free
     }
+    ATTN_MARK(1);
     // ---- projection: 64 rows x (16 NF) columns in four 16-row quarters ---------------------------------------------
 #pragma unroll 1
     for (int mq = 0; mq < 4; ++mq) {
@@ -142,77 +153,11 @@ __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* 
             pack_bf4((acc[j][0] + bq.x) * sc, (acc[j][1] + bq.y) * sc, (acc[j][2] + bq.z) * sc, (acc[j][3] + bq.w) * sc);
       }
     }
+    ATTN_MARK(2);
     srk_lds_barrier();                          // Bb: all q/k/v head tiles of the window are complete
-    // ---- attention: units u = wave, wave + 8, wave + 16 (u = 4 head + query tile) ----------------------------------
-    {
-      const int w = (int)(b_ % p.geom.nW);
-      const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
-      const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
-      unsigned char* aot = smem + (t & 1) * F_SLOT;            // the consumed xn1 slot becomes the ao tile [64][192]
-#pragma unroll 1
-      for (int k = 0; k < 3; ++k) {
-        const int u = wave + 8 * k, h = u >> 2, it = u & 3;
-        const bf16_t* Qs = tiles + (0 * F_NH + h) * F_TILE;
-        const bf16_t* Ks = tiles + (1 * F_NH + h) * F_TILE;
-        const bf16_t* Vs = tiles + (2 * F_NH + h) * F_TILE;
-        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * FT + 8 * g);
-        f32x4_t s[4];
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-          s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * FT + 8 * g), qf,
-                                                        f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) s[jt] += bnext[jt];
-        if (k < 2) load_bias(bnext, u + 8);     // next unit's bias: in flight under this unit's softmax and P.V
-        if (masked) {
-          const int labi = win_region_label(p.geom, w, 16 * it + r16);
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
-        }
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[jt][e]);
-        mx = xrow_max4(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s[jt][e] = __expf(s[jt][e] - mx);
-            sum += s[jt][e];
-          }
-        const float inv = 1.0f / xrow_sum4(sum);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[jt][e] *= inv;
-        f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const uint2 lo = pack_bf4(s[2 * ss][0], s[2 * ss][1], s[2 * ss][2], s[2 * ss][3]);
-          const uint2 hi = pack_bf4(s[2 * ss + 1][0], s[2 * ss + 1][1], s[2 * ss + 1][2], s[2 * ss + 1][3]);
-          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8_t vf = f_cat4(lds_tr_read(tr_addr(Vs, FT, 32 * ss + 4 * g, 16 * dt, lane)),
-                                       lds_tr_read(tr_addr(Vs, FT, 32 * ss + 16 + 4 * g, 16 * dt, lane)));
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
-          }
-        }
-        // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]: 8 consecutive d per lane after the 16-lane-row swap
-        const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
-        *reinterpret_cast<uint4*>(aot + ((16 * it + r16) * F_CA + h * 32 + (((g & 1) << 4) | ((g >> 1) << 3))) * 2) =
-            make_uint4(s0[0], s1[0], s0[1], s1[1]);
-      }
-    }
-    // ---- q / k / v tiles -> global for the backward pass: tile tl = wave, wave + 7, wave + 14 (waves 0..6) ------------
+    ATTN_MARK(3);
+    // ---- q / k / v tiles -> global for the backward pass, issued BEFORE the attention so that the 72 KB drain
+    // under its compute instead of arriving with the ao tile in one burst: tile tl = wave, wave + 7, wave + 14 (waves 0..6) ------------
     if constexpr (!LOADER) {
       if (p.qkv) {
 #pragma unroll 1
@@ -232,7 +177,70 @@ __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* 
         }
       }
     }
+    ATTN_MARK(4);
+    // ---- attention: units u = wave, wave + 8, wave + 16 (u = 4 head + query tile) ----------------------------------
+    {
+      const int w = (int)(b_ % p.geom.nW);
+      const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
+      const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
+      unsigned char* aot = smem + (t & 1) * F_SLOT;            // the consumed xn1 slot becomes the ao tile [64][192]
+#pragma unroll 1
+      for (int k = 0; k < 3; ++k) {
+        const int h = hw + 2 * k;                                // unit u = wave + 8 k = 4 h + it
+        UNIT_MARK(0);
+        const bf16_t* Qs = tiles + (0 * F_NH + h) * F_TILE;
+        const bf16_t* Ks = tiles + (1 * F_NH + h) * F_TILE;
+        const bf16_t* Vs = tiles + (2 * F_NH + h) * F_TILE;
+        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * FT + 8 * g);
+        f32x4_t s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * FT + 8 * g), qf,
+                                                        f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        UNIT_MARK(1);
+        {
+          const float* th = tabl + h * F_TAB;
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+            s[jt] += f32x4_t{th[93 - 30 * jt], th[92 - 30 * jt], th[91 - 30 * jt], th[90 - 30 * jt]};
+        }
+        if (masked) {
+          const int labi = win_region_label(p.geom, w, 16 * it + r16);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
+        }
+        UNIT_MARK(2);
+        bf16x8_t pf[2];
+        const float inv = softmax_numerators(s, pf);
+        UNIT_MARK(3);
+        f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8_t vf = f_cat4(lds_tr_read(tr_addr(Vs, FT, 32 * ss + 4 * g, 16 * dt, lane)),
+                                       lds_tr_read(tr_addr(Vs, FT, 32 * ss + 16 + 4 * g, 16 * dt, lane)));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ss], o[dt], 0, 0, 0);
+          }
+        }
+        o[0] *= inv;
+        o[1] *= inv;
+        UNIT_MARK(4);
+        // o[dt][e] = O[i = 16 it + r16][d = 16 dt + 4 g + e]: 8 consecutive d per lane after the 16-lane-row swap
+        const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        *reinterpret_cast<uint4*>(aot + ((16 * it + r16) * F_CA + h * 32 + (((g & 1) << 4) | ((g >> 1) << 3))) * 2) =
+            make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        UNIT_MARK(5);
+      }
+    }
+    ATTN_MARK(5);
     srk_lds_barrier();                          // Bc: the ao tile is complete; head tiles are no longer read
+    ATTN_MARK(6);
     if constexpr (!LOADER) {                    // the window's 24 KB of ao: 24 x 1 KB over waves 0..6
       const unsigned char* aot = smem + (t & 1) * F_SLOT;
       bf16_t* adst = p.ao + b_ * 64 * F_CA;
@@ -242,6 +250,7 @@ __device__ __forceinline__ void fused_wave(const FusedParams& p, unsigned char* 
         *reinterpret_cast<uint4*>(adst + idx * 8) = *reinterpret_cast<const uint4*>(aot + idx * 16);
       }
     }
+    ATTN_MARK(7);
   }
 }
 
@@ -253,8 +262,17 @@ __global__ __launch_bounds__(512) void qkv_attn_fwd_kernel(const FusedParams p) 
   if (nwin <= 0) return;
   // projection bias -> LDS once (no registers to spare for it; re-reading it from L2 per quarter put an exposed ~1 us
   // round trip into every quarter); visible to everyone after the first barrier of the window loop
-  float* pbias = reinterpret_cast<float*>(smem + 2 * F_SLOT + 18 * F_TILE * 2);
+  float* pbias = reinterpret_cast<float*>(smem + F_OFF_PBIAS);
   for (int i = tid; i < 3 * F_CA; i += 512) pbias[i] = p.bias ? p.bias[i] : 0.f;
+  // rel-pos bias table [6][225] out of the dense [6][64][64] (offset (dy, dx) is realised by the pair i = (max(dy, 0), max(dx, 0)),
+  // j = (max(-dy, 0), max(-dx, 0))): 5.4 KB of LDS instead of an L2 round trip per unit, which was what paced the attention phase
+  float* tab = reinterpret_cast<float*>(smem + F_OFF_TAB);
+  for (int i = tid; i < F_NH * F_TAB; i += 512) {
+    const int h = i / F_TAB, t = i - h * F_TAB;
+    const int dy = t / 15 - 7, dx = t - (t / 15) * 15 - 7;
+    const int qi = (dy > 0 ? dy : 0) * 8 + (dx > 0 ? dx : 0), kj = (dy < 0 ? -dy : 0) * 8 + (dx < 0 ? -dx : 0);
+    tab[i] = p.biasd[h * 4096 + qi * 64 + kj];
+  }
   if (wave < 4) fused_wave<5, false>(p, smem, wave, lane, nwin);
   else if (wave < 7) fused_wave<4, false>(p, smem, wave, lane, nwin);
   else fused_wave<4, true>(p, smem, wave, lane, nwin);

@@ -42,8 +42,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// one v_cvt_pk_bf16_f32 (two scalar conversions + shift + or cost four VALU slots per pair)
+typedef __bf16 srk_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float srk_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(srk_f32x2_t{lo, hi}, srk_bf16x2_t));
 }
 
 __device__ __forceinline__ uint2 pack_bf4(float a, float b, float c, float d) {
@@ -197,6 +200,36 @@ __device__ __forceinline__ float xrow_sum4(float v) {
   v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
   const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Softmax numerators of one 16-query x 64-key score tile held as four MFMA accumulators (s[jt][e] = S[query r16][key
+// 16 jt + 4 g + e], bias and mask already added).  Returns exp(s - rowmax) -- in [0, 1], UNNORMALISED -- as the two bf16
+// B-operand fragments of P (k = key) and 1 / row sum: the caller scales its 8 outputs instead of the 64 probabilities.
+// exp(x - m) = exp2(x log2e - m log2e): one packed fma per two scores + v_exp_f32, v_rcp_f32 for the sum (the phase is
+// VALU-issue-bound: 4 cycles per wave-instruction, 8 for a transcendental).
+__device__ __forceinline__ float softmax_numerators(const f32x4_t (&s)[4], bf16x8_t (&pf)[2]) {
+  constexpr float L2E = 1.4426950408889634f;
+  float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+  for (int jt = 1; jt < 4; ++jt) mx = fmaxf(fmaxf(mx, s[jt][0]), fmaxf(fmaxf(s[jt][1], s[jt][2]), s[jt][3]));
+  mx = xrow_max4(mx);
+  const float mxl = mx * L2E;
+  f32x4_t e[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const f32x4_t t = s[jt] * L2E - mxl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[jt][k] = __builtin_amdgcn_exp2f(t[k]);
+  }
+  const f32x4_t a = (e[0] + e[1]) + (e[2] + e[3]);
+  const float sum = xrow_sum4((a[0] + a[1]) + (a[2] + a[3]));
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) {
+    const uint2 lo = pack_bf4(e[2 * ss][0], e[2 * ss][1], e[2 * ss][2], e[2 * ss][3]);
+    const uint2 hi = pack_bf4(e[2 * ss + 1][0], e[2 * ss + 1][1], e[2 * ss + 1][2], e[2 * ss + 1][3]);
+    pf[ss] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+  }
+  return __builtin_amdgcn_rcpf(sum);
 }
 
 __device__ __forceinline__ float wave_sum64(float v) {
