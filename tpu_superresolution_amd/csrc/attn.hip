@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
     *reinterpret_cast<uint4*>(Ks + srow * TS + sch * 8) = prek;
     *reinterpret_cast<uint4*>(Vs + srow * TS + sch * 8) = prev;
     *reinterpret_cast<uint4*>(Os + srow * TS + sch * 8) = preo;
-    __syncthreads();
+    srk_lds_barrier();      // LDS only: no vmcnt(0) drain of the prefetch loads / dqkv stores in flight
     if (wi + 1 < wpw && b_ + 1 < B_) ATTN_BWD_PREFETCH(b_ + 1);
 
     // ---- phase 1: this wave's 16 queries (it = wave) against all 64 keys -----------------------
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
         *reinterpret_cast<uint2*>(Db + (16 * it + r16) * PS + 16 * jt + 4 * g) = pack_bf4(dp[jt][0], dp[jt][1], dp[jt][2], dp[jt][3]);
       }
     }
-    __syncthreads();
+    srk_lds_barrier();      // LDS only: no vmcnt(0) drain of the prefetch loads / dqkv stores in flight
 
     // ---- phase 2: this wave's 16 keys (jt = wave) for dV / dK, its 16 queries for dQ --------------
     {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
       store8(row + CA, pack_bf4(ak[0][0], ak[0][1], ak[0][2], ak[0][3]), pack_bf4(ak[1][0], ak[1][1], ak[1][2], ak[1][3]));
       store8(row + 2 * CA, pack_bf4(av[0][0], av[0][1], av[0][2], av[0][3]), pack_bf4(av[1][0], av[1][1], av[1][2], av[1][3]));
     }
-    __syncthreads();
+    srk_lds_barrier();      // LDS only: no vmcnt(0) drain of the prefetch loads / dqkv stores in flight
   }
 
   // per-workgroup partial d(bias) slab, dense [i][j]; this wave owns the rows i = 16 wave + r16

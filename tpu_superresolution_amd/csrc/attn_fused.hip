@@ -278,12 +278,213 @@ __global__ __launch_bounds__(512) void qkv_attn_fwd_kernel(const FusedParams p) 
   else fused_wave<4, true>(p, smem, wave, lane, nwin);
 }
 
-int g_attn_fused = 1;
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Second shape of the same fusion: THREE 4-wave workgroups per CU, each owning one head pair (64 of the 192 attention channels)
+// of the windows it walks.  Phase timestamps of the 8-wave kernel above (tools/attn_probe.py) show its window as a chain of
+// latency-bound phases -- projection 2.8 us (MFMA pipe, VALU idle), attention 2.4-3.2 us (one dependent chain per wave: LDS ->
+// MFMA -> softmax -> MFMA -> store, the SIMD two-thirds idle), stores -- with every wave of the CU in the same phase.  Three
+// independent workgroups per CU drift apart, so one's projection MFMAs run under another's softmax and a third's stores, and
+// each SIMD has three waves to pick from.  Per workgroup and window:
+//   xn1 rows    64 x 192 bf16 (24 KB) prefetched into registers one window ahead (default cache policy: the two sibling
+//               workgroups of the window sit on the same XCD and find the rows in its L2), then written XOR-swizzled to LDS
+//   projection  192 output columns (q, k, v of two heads) = 12 fragments, three per wave with W in registers (72 VGPRs)
+//   head tiles  six [64][32] bf16 tiles, 16-byte chunks XOR-swizzled with (row >> 2) & 3 instead of padded (3 x 51 KB of LDS)
+//   attention   two units per wave (head 0 / 1 of the pair, query tile = wave), as above; ao goes to global from registers
+// Two barriers per window.  Grid = 24 g workgroups: id -> xcd = id & 7, slot = id >> 3, head pair = slot % 3, group = slot / 3;
+// the workgroup walks windows (8 group + xcd) + 8 g t.
+constexpr int G_TILE = 64 * 32;                                       // elements per swizzled head tile
+constexpr int G_OFF_TILES = F_SLOT;
+constexpr int G_OFF_PBIAS = G_OFF_TILES + 6 * G_TILE * 2;
+constexpr int G_OFF_TAB = G_OFF_PBIAS + 192 * 4;
+constexpr int G_LDS = G_OFF_TAB + 2 * F_TAB * 4;                      // 51 720 B
+
+__device__ __forceinline__ int g_tile_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); }   // elements
+
+__global__ __launch_bounds__(256, 3) void qkv_attn_fwd3_kernel(const FusedParams p, int ngrp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int hp = slot % 3, grp = slot / 3;
+  const long long first = (long long)grp * 8 + xcd, stride = (long long)ngrp * 8;
+  if (first >= p.B_) return;
+  const long long nwin = (p.B_ - first + stride - 1) / stride;
+
+  bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + G_OFF_TILES);       // [which][head of the pair][64][32] swizzled
+  float* pbias = reinterpret_cast<float*>(smem + G_OFF_PBIAS);        // [12 fragments][16]
+  float* tab = reinterpret_cast<float*>(smem + G_OFF_TAB);            // [2][225]
+  for (int i = tid; i < 192; i += 256) {
+    const int lf = i >> 4, which = lf >> 2, hl = (lf >> 1) & 1, half = lf & 1;
+    pbias[i] = p.bias ? p.bias[which * F_CA + (2 * hp + hl) * 32 + half * 16 + (i & 15)] : 0.f;
+  }
+  for (int i = tid; i < 2 * F_TAB; i += 256) {                        // table out of the dense bias, as in the kernel above
+    const int hl = i / F_TAB, t = i - hl * F_TAB;
+    const int dy = t / 15 - 7, dx = t - (t / 15) * 15 - 7;
+    const int qi = (dy > 0 ? dy : 0) * 8 + (dx > 0 ? dx : 0), kj = (dy < 0 ? -dy : 0) * 8 + (dx < 0 ? -dx : 0);
+    tab[i] = p.biasd[(2 * hp + hl) * 4096 + qi * 64 + kj];
+  }
+
+  // W slice of this wave: local fragments lf = 3 wave + j -> (which, head of the pair, 16-column half)
+  bf16x8_t wf[3][6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int lf = 3 * wave + j, which = lf >> 2, hl = (lf >> 1) & 1, half = lf & 1;
+    const bf16_t* wr = p.Wt + (long long)(which * F_CA + (2 * hp + hl) * 32 + half * 16 + r16) * F_K;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) wf[j][s] = *reinterpret_cast<const bf16x8_t*>(wr + s * 32 + g * 8);
+  }
+
+  // xn1 staging: thread = (row = tid >> 2, cq = tid & 3) moves the 16-byte chunks 4 i + cq, i < 6, of its row (64 contiguous
+  // bytes per row and instruction); two halves of three chunks, each held in registers only between its load and its LDS write.
+  // swizzled chunk (4 i + cq) ^ (row & 7) = 8 (i >> 1) + ((cq ^ (row & 7)) ^ 4 (i & 1))
+  const int srow = tid >> 2, scq = tid & 3;
+  const long long grow = (long long)srow * p.lda + scq * 8;
+  const int lrow = srow * (F_K * 2), lc0 = (scq ^ (srow & 7)) << 4, lc1 = lc0 ^ 64;
+  uint4 pre0, pre1, pre2;
+#define G_PREFETCH(BW, HALF)                                                                     \
+  do {                                                                                           \
+    const bf16_t* base_ = p.xn + (BW) * 64 * (long long)p.lda + grow + (HALF) * 96;              \
+    pre0 = *reinterpret_cast<const uint4*>(base_);                                               \
+    pre1 = *reinterpret_cast<const uint4*>(base_ + 32);                                          \
+    pre2 = *reinterpret_cast<const uint4*>(base_ + 64);                                          \
+  } while (0)
+  // chunks ii = 3 HALF + i: HALF 0 -> (0: lc0) (1: lc1) (2: 128 + lc0); HALF 1 -> (3: 128 + lc1) (4: 256 + lc0) (5: 256 + lc1)
+#define G_STAGE(HALF)                                                                            \
+  do {                                                                                           \
+    unsigned char* d_ = smem + lrow;                                                             \
+    if ((HALF) == 0) {                                                                           \
+      *reinterpret_cast<uint4*>(d_ + lc0) = pre0;                                                \
+      *reinterpret_cast<uint4*>(d_ + lc1) = pre1;                                                \
+      *reinterpret_cast<uint4*>(d_ + 128 + lc0) = pre2;                                          \
+    } else {                                                                                     \
+      *reinterpret_cast<uint4*>(d_ + 128 + lc1) = pre0;                                          \
+      *reinterpret_cast<uint4*>(d_ + 256 + lc0) = pre1;                                          \
+      *reinterpret_cast<uint4*>(d_ + 256 + lc1) = pre2;                                          \
+    }                                                                                            \
+  } while (0)
+  G_PREFETCH(first, 0);
+  G_STAGE(0);
+  G_PREFETCH(first, 1);
+  G_STAGE(1);
+
+  const int it = wave;
+  const float* tabl = tab + ((2 * it + (r16 >> 3)) - (g >> 1) + 7) * 15 + ((r16 & 7) - 4 * (g & 1) + 7) - 93;
+
+  for (long long t = 0; t < nwin; ++t) {
+    const long long b_ = first + t * stride;
+    srk_lds_barrier();                          // A: xn1 rows of window t (and, first time, bias + table) are in LDS; tiles are free
+    const bool more = t + 1 < nwin;
+    if (more) G_PREFETCH(b_ + stride, 0);
+    // ---- projection: 64 rows x 48 columns per wave in four 16-row quarters ----------------------------------------------
+#pragma unroll 1
+    for (int mq = 0; mq < 4; ++mq) {
+      f32x4_t acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * mq + r16;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(smem + row * (F_K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int lf = 3 * wave + j, which = lf >> 2, hl = (lf >> 1) & 1, half = lf & 1;
+        const float sc = which == 0 ? p.scale : 1.0f;
+        const float4 bq = *reinterpret_cast<const float4*>(pbias + 16 * lf + 4 * g);
+        *reinterpret_cast<uint2*>(tiles + (which * 2 + hl) * G_TILE + g_tile_off(row, 2 * half + (g >> 1)) + 4 * (g & 1)) =
+            pack_bf4((acc[j][0] + bq.x) * sc, (acc[j][1] + bq.y) * sc, (acc[j][2] + bq.z) * sc, (acc[j][3] + bq.w) * sc);
+      }
+    }
+    srk_lds_barrier();                          // B: the six head tiles are complete; the xn1 rows are no longer read
+    if (more) {
+      G_STAGE(0);
+      G_PREFETCH(b_ + stride, 1);
+    }
+    // ---- q / k / v -> global for the backward pass: thread = (row, 16-byte chunk) of each tile --------------------------------
+    if (p.qkv) {
+      const int row = tid >> 2, ch = tid & 3;
+#pragma unroll
+      for (int tl = 0; tl < 6; ++tl) {
+        const uint4 t4 = *reinterpret_cast<const uint4*>(tiles + tl * G_TILE + g_tile_off(row, ch));
+        bf16_t* dst = p.qkv + (((tl >> 1) * p.B_ + b_) * F_NH + 2 * hp + (tl & 1)) * 2048 + row * 32 + ch * 8;
+        if constexpr (SRK_NT_STORE_QKV != 0)
+          __builtin_nontemporal_store(srk_u4{t4.x, t4.y, t4.z, t4.w}, reinterpret_cast<srk_u4*>(dst));
+        else
+          *reinterpret_cast<uint4*>(dst) = t4;
+      }
+    }
+    // ---- attention: head hl of the pair, query tile it = wave ------------------------------------------------------------------
+    {
+      const int w = (int)(b_ % p.geom.nW);
+      const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
+      const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
+#pragma unroll 1
+      for (int hl = 0; hl < 2; ++hl) {
+        const bf16_t* Qs = tiles + (0 + hl) * G_TILE;
+        const bf16_t* Ks = tiles + (2 + hl) * G_TILE;
+        const bf16_t* Vs = tiles + (4 + hl) * G_TILE;
+        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + g_tile_off(16 * it + r16, g));
+        f32x4_t s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + g_tile_off(16 * jt + r16, g)), qf,
+                                                        f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        {
+          const float* th = tabl + hl * F_TAB;
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+            s[jt] += f32x4_t{th[93 - 30 * jt], th[92 - 30 * jt], th[91 - 30 * jt], th[90 - 30 * jt]};
+        }
+        if (masked) {
+          const int labi = win_region_label(p.geom, w, 16 * it + r16);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
+        }
+        bf16x8_t pf[2];
+        const float inv = softmax_numerators(s, pf);
+        f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        // V^T fragments: lane 4 q + c of a 16-lane group supplies row (key) rb + q, columns 16 dt + 4 c .. + 3; the rows of one
+        // transposing read share (row >> 2) & 3 = g, so its chunk swizzle is a lane-group constant
+        const int ll = lane & 15;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int ch = ((2 * dt + ((ll & 3) >> 1)) ^ g) << 3, in = (ll & 1) << 2;
+            const bf16x8_t vf = f_cat4(lds_tr_read(Vs + (32 * ss + 4 * g + (ll >> 2)) * 32 + ch + in),
+                                       lds_tr_read(Vs + (32 * ss + 16 + 4 * g + (ll >> 2)) * 32 + ch + in));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ss], o[dt], 0, 0, 0);
+          }
+        }
+        o[0] *= inv;
+        o[1] *= inv;
+        const uint2 x = pack_bf4(o[0][0], o[0][1], o[0][2], o[0][3]), y = pack_bf4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
+        *reinterpret_cast<uint4*>(p.ao + (b_ * 64 + 16 * it + r16) * F_CA + (2 * hp + hl) * 32 + (((g & 1) << 4) | ((g >> 1) << 3))) =
+            make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+    }
+    if (more) G_STAGE(1);
+  }
+}
+
+#ifndef SRK_ATTN_FUSED_DEFAULT
+#define SRK_ATTN_FUSED_DEFAULT 2
+#endif
+int g_attn_fused = SRK_ATTN_FUSED_DEFAULT;            // 0 separate kernels, 1 one 8-wave workgroup per CU, 2 three 4-wave workgroups per CU
 int g_fused_cus = 0;
 
 }  // namespace
 
-void srk_attn_fused_enable(int on) { g_attn_fused = on ? 1 : 0; }
+void srk_attn_fused_enable(int on) { g_attn_fused = on < 0 ? 0 : (on > 2 ? 2 : on); }
 
 // SRK_NOT_COVERED (1) when the fused kernel does not apply: the caller then runs the projection GEMM and srk_launch_attn_fwd.
 int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const float* bias, float scale, bf16_t* qkv,
@@ -314,10 +515,25 @@ int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const f
       configured = 1;
     }
   }
+  static int configured3 = 0;
+  if (!configured3) {
+    const void* fn = reinterpret_cast<const void*>(&qkv_attn_fwd3_kernel);
+    hipFuncAttributes attr;
+    configured3 = -1;
+    if (hipFuncGetAttributes(&attr, fn) == hipSuccess && attr.localSizeBytes == 0 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) == hipSuccess)
+      configured3 = 1;
+  }
   if (configured < 0) return SRK_NOT_COVERED;
   FusedParams fp;
   fp.xn = xn; fp.lda = lda; fp.Wt = Wt; fp.bias = bias; fp.scale = scale; fp.qkv = qkv; fp.biasd = biasd; fp.ao = ao; fp.B_ = B_;
   fp.geom = geom;
+  if (g_attn_fused == 2 && configured3 > 0) {
+    long long ngrp = g_fused_cus / 8;                       // 24 workgroups per group of 8 windows in flight: 3 per CU
+    if (ngrp * 8 > B_) ngrp = (B_ + 7) / 8;
+    hipLaunchKernelGGL(qkv_attn_fwd3_kernel, dim3((unsigned)(24 * ngrp)), dim3(256), G_LDS, stream, fp, (int)ngrp);
+    return srk_check_launch("qkv+attention (3 per CU)");
+  }
   hipLaunchKernelGGL(qkv_attn_fwd_kernel, dim3(g_fused_cus), dim3(512), F_LDS, stream, fp);
   return srk_check_launch("qkv+attention");
 }

@@ -643,14 +643,14 @@ __global__ __launch_bounds__(256) void imghead_dgrad_mfma_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<uint2*>(T + (16 * wave + r16) * TP + 16 * j + 4 * g) = pack_bf4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-    __syncthreads();
+    srk_lds_barrier();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int pid = tid + 256 * t;
       const int row = pid >> 3, c8 = pid & 7;
       *reinterpret_cast<uint4*>(dx + ((long long)c * 64 + row) * 64 + c8 * 8) = *reinterpret_cast<const uint4*>(T + row * TP + c8 * 8);
     }
-    __syncthreads();
+    srk_lds_barrier();
   }
 }
 

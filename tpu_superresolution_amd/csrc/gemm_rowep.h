@@ -107,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
 
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    if (half) __syncthreads();
+    if (half) srk_lds_barrier();      // LDS hazard only: a __syncthreads() would also wait for the first half's global stores
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -120,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
       if (half == 0)
         for (int i = tid; i < 2 * BN; i += 256) colred[i] = 0.f;
     }
-    __syncthreads();
+    srk_lds_barrier();
     // Global operands of the row epilogue are fetched for a batch of rows BEFORE any of them is consumed: the
     // compiler cannot hoist these loads above the previous row's stores (possible aliasing), and at 2 workgroups
     // per CU a dependent load-use-store chain per row would serialise ~8 memory round trips per tile.
