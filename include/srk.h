@@ -105,8 +105,9 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1, "gemm_stream_nb" 0/4/8:
  *   tile-shape overrides of that kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
  *   "probe_stride" 1..1024: see srk_probe_begin.
- *   "attn_fused" 1 (default) / 0: qkv projection + window attention forward in one kernel per window
- *   (csrc/attn_fused.hip; classical width: 6 heads x 32, C padded to 192) or the projection GEMM + attention kernel.
+ *   "attn_fused" 2 (default) / 1 / 0: qkv projection + window attention forward in one kernel per window
+ *   (csrc/attn_fused.hip; classical width: 6 heads x 32, C padded to 192) as three 4-wave workgroups per CU (2) or one 8-wave
+ *   workgroup per CU (1), or the projection GEMM + attention kernel (0).
  *   "wgrad_stream" 1 (default) / 0: LDS-DMA ring variant of the 192x192 linear weight-gradient tile or the
  *   register-staged one (both in csrc/wgrad.hip).
  *   "conv_wgrad_taps" 2 (default) / 1 / 0: all-taps conv weight gradient with the LDS-DMA ring / register-staged
