@@ -12,6 +12,7 @@
 // Operands that are needed "transposed" (V^T, Q^T, K^T, dO^T, P, dS) are read from small
 // wave-private LDS tiles with ds_read_b64_tr_b16.
 #include "common.h"
+#include "wgrad.h"
 
 namespace {
 
@@ -382,32 +383,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restri
         make_float4(dbias[jt][0], dbias[jt][1], dbias[jt][2], dbias[jt][3]);
 }
 
-// One workgroup per (query token i, head h): the 4 waves sum row i of every slab (256-B coalesced reads, lane = key
-// token j), combine through LDS, and scatter the 64 row sums into the table with rpi(i, j).
 __global__ __launch_bounds__(256) void rpb_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dtable,
                                                          int nslab, int nH) {
   __shared__ float part[4][64];
-  const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // eight independent loads in flight per wave: one dependent load per iteration made this kernel a chain of ~32 memory
-  // round trips (15 us for 12 MB)
-  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const long long sstride = (long long)nH * 4096;
-  const float* base = slab + ((long long)h * 64 + i) * 64 + lane;
-  int sidx = wave;
-  for (; sidx + 28 < nslab; sidx += 32) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a8[u] += base[(sidx + 4 * u) * sstride];
-  }
-  for (; sidx < nslab; sidx += 4) a8[0] += base[sidx * sstride];
-  const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-  part[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0) {
-    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-    // rpi(i,j) = (yi-yj+7)*15 + (xi-xj+7)
-    const int t = ((i >> 3) - (lane >> 3) + 7) * 15 + ((i & 7) - (lane & 7) + 7);
-    atomicAdd(dtable + t * nH + h, v);
-  }
+  rpb_reduce_block(slab, dtable, nslab, nH, blockIdx.x, blockIdx.y, part);     // wgrad.h
 }
 
 // dense bias[h][i][j] = table[rpi(i,j)][h]   (network_swinir.py:127-129)
@@ -455,8 +434,12 @@ int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao
                      wpw, scale);
   srk_probe_post(FAM_ATTN_BWD, stream);
   int rc = srk_check_launch("attn_bwd");
-  if (rc) return rc;
-  hipLaunchKernelGGL(rpb_reduce_kernel, dim3(64, nH), dim3(256), 0, stream, dbias_slab, dtable, nslab, nH);
+  if (rc || dtable == nullptr) return rc;      // dtable == null: the caller reduces the slabs later (RpbJob, wgrad.h)
+  return srk_launch_rpb_reduce(dbias_slab, dtable, nslab, nH, stream);
+}
+
+int srk_launch_rpb_reduce(const float* slab, float* dtable, int nslab, int nH, hipStream_t stream) {
+  hipLaunchKernelGGL(rpb_reduce_kernel, dim3(64, nH), dim3(256), 0, stream, slab, dtable, nslab, nH);
   return srk_check_launch("rpb_reduce");
 }
 

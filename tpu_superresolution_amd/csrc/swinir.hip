@@ -1172,10 +1172,12 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
         }
         wq[2] = lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj, fl_proj);
+        // the slabs of d(bias) are reduced into the table gradient by the reduce launch of the weight gradients below
         RUN(srk_launch_attn_bwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(w.dao), c.at<bf16_t>(w.dqkv),
-                                c.at<float>(w.slab), grads + bw.rpb, T / 64, bw.nH, geom, bw.scale, st));
+                                c.at<float>(w.slab), nullptr, T / 64, bw.nH, geom, bw.scale, st));
+        const RpbJob rpb = {c.at<float>(w.slab), grads + bw.rpb, srk_attn_bwd_slabs(T / 64, bw.nH, nullptr), bw.nH};
         wq[3] = lin_wgrad(c, c.at<bf16_t>(w.dqkv), 3 * bw.CA, c.at<bf16_t>(ba.xn1w), CP, T, bw.Wqkv, bw.bqkv, fl_qkv);
-        RUN(srk_launch_wgrad_multi(wq, 4, st));   // reads gxb2 (as d x2): must precede the kernel that overwrites it
+        RUN(srk_launch_wgrad_multi_rpb(wq, 4, &rpb, st));   // reads gxb2 (as d x2): must precede the kernel that overwrites it
         {  // d xn1 (window order) = d qkv . Wqkv
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.dqkv); g.lda = 3 * bw.CA; g.Wt = c.packed + bw.WqkvT; g.M = T; g.N = CP; g.K = 3 * bw.CA;

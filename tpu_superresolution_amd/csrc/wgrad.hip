@@ -336,6 +336,12 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
 // Sum of the nsplit partial tiles of wgrad_stream_kernel, added to dW.  One thread per accumulator vector
 // (9216 per tile), 36 workgroups per tile; the partials are read as 1-KiB wave rows, 8 splits in flight.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradMulti mp) {
+  if ((int)blockIdx.x >= 36 * mp.tile_begin[mp.nprob]) {        // riding job: 64 nH workgroups after the tile workgroups
+    __shared__ float part[4][64];
+    const int b = blockIdx.x - 36 * mp.tile_begin[mp.nprob];
+    rpb_reduce_block(mp.rpb.slab, mp.rpb.dtable, mp.rpb.nslab, mp.rpb.nH, b & 63, b >> 6, part);
+    return;
+  }
   const int btile = blockIdx.x / 36;
   const int q = (blockIdx.x - btile * 36) * 256 + threadIdx.x;
   int pi = 0;
@@ -364,6 +370,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradMulti mp) 
   for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + k, sum[e]);
 }
 
+thread_local const RpbJob* t_rpb = nullptr;     // job offered by srk_launch_wgrad_multi_rpb to the next reduce launch of this thread
+thread_local bool t_rpb_done = false;
+
 int g_wgrad_stream = 1;
 int g_wgrad_rows = 32;      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
 int g_wgrad_nt = 1;         // nt (streaming) cache policy on its operand DMAs
@@ -385,6 +394,7 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   mp.nprob = nprob;
   mp.partial = nullptr;
   mp.nsplit = 0;
+  mp.rpb = RpbJob{nullptr, nullptr, 0, 0};
   int tiles = 0;
   double flops = 0.0, bytes = 0.0;
   for (int i = 0; i < nprob; ++i) {
@@ -426,7 +436,15 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
       mp.partial = g_wgrad_partials && splits > 1 ? srk_wgrad_scratch(stream, (size_t)tiles * splits * WS_SLAB_VEC * 16) : nullptr;
       srk_probe_pre(fam, stream, flops, bytes);
       hipLaunchKernelGGL(fn, dim3(tiles * splits), dim3(256), slds, stream, mp);
-      if (mp.partial) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tiles * 36), dim3(256), 0, stream, mp);
+      if (mp.partial) {
+        int extra = 0;
+        if (t_rpb && t_rpb->slab) {
+          mp.rpb = *t_rpb;
+          extra = 64 * t_rpb->nH;
+          t_rpb_done = true;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tiles * 36 + extra), dim3(256), 0, stream, mp);
+      }
       srk_probe_post(fam, stream);
       return srk_check_launch("wgrad(stream)");
     }
@@ -502,6 +520,15 @@ int srk_launch_wgrad(const WgradParams& p, hipStream_t stream) {
 
 // Up to 4 linear problems with the same M.  Problems of the same tile class go out as one launch (so that the
 // launch fills the chip with few m-splits, i.e. few atomic passes); the rest are launched one by one.
+int srk_launch_wgrad_multi_rpb(const WgradParams* ps, int nprob, const RpbJob* rpb, hipStream_t stream) {
+  t_rpb = rpb;
+  t_rpb_done = false;
+  int rc = srk_launch_wgrad_multi(ps, nprob, stream);
+  t_rpb = nullptr;
+  if (rc == SRK_OK && rpb && rpb->slab && !t_rpb_done) rc = srk_launch_rpb_reduce(rpb->slab, rpb->dtable, rpb->nslab, rpb->nH, stream);
+  return rc;
+}
+
 int srk_launch_wgrad_multi(const WgradParams* ps, int nprob, hipStream_t stream) {
   SRK_REQUIRE(nprob >= 1 && nprob <= 4, SRK_E_SHAPE, "wgrad_multi: nprob=%d", nprob);
   bool same = true;
