@@ -336,3 +336,32 @@ def test_default_init_cfg3_meets_the_survey_tolerance():
     assert float(ref.abs().max()) <= 1.0
     assert float((y - ref).abs().max()) <= 5e-3
     assert mutual_psnr(y, ref) >= 60.0
+
+
+def test_light_whole_block_kernel_matches_layer_per_launch_path():
+    """csrc/block_light.hip (one kernel per Swin block at the light width, inference) against the layer-per-launch path: the same
+    rounding points, another summation order in the proj GEMM (compact K = 96 instead of the head-padded 192) -> equal up to the
+    bf16 flips that causes; shifted and unshifted blocks, masked border windows, a non-multiple-of-8 input (reflect pad)."""
+    from tpu_superresolution_amd._lib import check, lib
+    cfg = O.SwinIRConfig.light_x2()
+    sd = O.random_state_dict(cfg, seed=3, scale=1.0)
+    outs = {}
+    try:
+        for on in (1, 0):
+            check(lib().srk_set_option(b"block_light", on))
+            m = build(cfg, sd)
+            outs[on] = []
+            for shape in ((4, 3, 48, 48), (2, 3, 40, 52)):
+                x = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[2])).cuda()
+                with torch.no_grad():
+                    outs[on].append(m(x).float().cpu())
+    finally:
+        check(lib().srk_set_option(b"block_light", 1))
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 4e-3 * float(b.abs().max())
+    x = torch.rand(2, 3, 48, 48, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = O.swinir_forward(sd, cfg, x)
+        got = build(cfg, sd)(x.cuda()).float().cpu()
+    assert float((got - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())

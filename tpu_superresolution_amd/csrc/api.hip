@@ -253,6 +253,10 @@ int srk_set_option(const char* name, int value) {
     srk_attn_fused_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "block_light") == 0) {
+    srk_block_light_enable(value);
+    return SRK_OK;
+  }
   if (strcmp(name, "mlp_fused") == 0) {
     srk_mlp_fused_enable(value);
     return SRK_OK;

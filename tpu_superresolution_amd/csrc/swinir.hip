@@ -711,6 +711,18 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
       const WinGeom geom = make_wgeom(H, W, bw.shift);
       const float* ds_attn = drop_scale ? drop_scale + ((size_t)bi * 2 + 0) * B : nullptr;
       const float* ds_mlp = drop_scale ? drop_scale + ((size_t)bi * 2 + 1) * B : nullptr;
+      if (!w.training) {   // light width, inference: the whole block is one kernel (block_light.hip); it normalises its own rows
+        const int rc_light = srk_launch_swin_block_light(
+            c.at<float>(ba.x_in), c.at<float>(ba.x_out), (j == depth - 1) ? c.at<bf16_t>(w.layer_xb[l]) : nullptr, params + bw.n1w,
+            params + bw.n1b, params + bw.n2w, params + bw.n2b, c.packed + bw.Wqkv, c.packed + bw.Wproj, c.packed + bw.Wfc1,
+            c.packed + bw.Wfc2, c.side + bw.bqkv, c.side + bw.bproj, c.side + bw.bfc1, c.side + bw.bfc2, c.side + bw.biasd, bw.scale, C,
+            CP, HP, bw.nH, bw.dh, T / 64, geom, st);
+        if (rc_light != SRK_NOT_COVERED) {
+          RUN(rc_light);
+          ln1_done = false;
+          continue;
+        }
+      }
       // LN1 (+ roll + window partition)            network_swinir.py:245-256
       // (normally already produced by the epilogue of the kernel that wrote x_in: fc2 of the previous block / RSTB conv)
       if (!ln1_done)
