@@ -105,6 +105,9 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1, "gemm_stream_nb" 0/4/8:
  *   tile-shape overrides of that kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
  *   "probe_stride" 1..1024: see srk_probe_begin.
+ *   "block_light" 1 (default) / 0: SwinIR-light width (C <= 64, 6 heads x d <= 16, hidden <= 128), inference: each Swin block is
+ *   ONE kernel (csrc/block_light.hip: LayerNorms, qkv, window attention, proj, MLP and both residuals of a window in LDS and
+ *   registers) or the layer-per-launch path.
  *   "attn_fused" 2 (default) / 1 / 0: qkv projection + window attention forward in one kernel per window
  *   (csrc/attn_fused.hip; classical width: 6 heads x 32, C padded to 192) as three 4-wave workgroups per CU (2) or one 8-wave
  *   workgroup per CU (1), or the projection GEMM + attention kernel (0).

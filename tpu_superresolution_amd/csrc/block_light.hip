@@ -9,29 +9,33 @@
 // launches of a few microseconds of work each (cfg2: 83 us per block at 1.4 % of the MFMA peak, latency all the way); here a
 // block is one launch, one read and one write of the residual stream ("each Swin block is ONE kernel").
 //
-// One 512-thread workgroup per window, two workgroups per CU (80 KB of LDS, <= 128 VGPRs).  Phases (a barrier between each):
-//   0  rows of the window gathered through the roll + window-partition map, LayerNorm1 -> Xn (bf16, swizzled), x -> X (fp32)
-//   1  projection: 18 live 16-column fragments (q, k, v x 6 heads), W in registers, + bias, q scaled -> head tiles [64][16]
-//   2  attention: 24 (head, 16-query tile) units, three per wave; K = 16 of the 32-deep MFMA (lanes k >= 16 feed zeros),
-//      rel-pos bias from the 225-entry table in LDS, softmax_numerators, P.V on the 16 live columns -> ao [64][6 x 16]
-//   3  proj over the compact K = 96 (+ bias + residual) -> X
-//   4  LayerNorm2 -> Xn
+// One 256-thread workgroup per window, three workgroups per CU (53 KB of LDS, <= 168 VGPRs): a window is a chain of eight short
+// dependent phases, so what fills the CU is independent windows, not more waves per window (512-thread workgroups at two per CU
+// needed two rounds for cfg2's 576 windows: 39 us per block against 2 x 19.5 us per workgroup).  The residual rows live in
+// registers (row layout: thread = 4 channels of rows tid >> 4 + 16 i); GEMM results in MFMA layout reach them through an fp32
+// exchange tile on top of the dead head tiles.  Phases (a barrier between each):
+//   0  rows of the window gathered through the roll + window-partition map, LayerNorm1 -> Xn (bf16, swizzled)
+//   1  projection: 18 live 16-column fragments (q, k, v x 6 heads; 5 / 5 / 4 / 4 per wave), W in registers, + bias, q scaled
+//      -> head tiles [64][16]
+//   2  attention: 24 (head, 16-query tile) units, six per wave; K = 16 of the 32-deep MFMA (lanes k >= 16 feed zeros),
+//      rel-pos bias rows from the dense table (L2, one head ahead), softmax_numerators, P.V on the 16 live columns -> ao [64][6 x 16]
+//   3  proj over the compact K = 96 -> exchange tile E
+//   4  x1 = x + E + bias (registers), LayerNorm2 -> Xn
 //   5  fc1 + bias + GELU -> H [64][128] (bf16, swizzled)
-//   6  fc2 + bias + residual -> X
-//   7  X rows -> global through the inverse map (256-byte rows), optional bf16 copy for the RSTB conv
+//   6  fc2 -> exchange tile E2
+//   7  x2 = x1 + E2 + bias -> global through the inverse map (256-byte rows), optional bf16 copy for the RSTB conv
 // Rounding points are those of the layer-per-launch path (LN outputs, q/k/v, P, attention output, hidden: bf16; residual
 // stream fp32).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace {
 
-constexpr int L_OFF_X = 0;             // fp32 [64][64]
-constexpr int L_OFF_XN = 16384;        // bf16 [64][64], chunk ^ (row & 7)
-constexpr int L_OFF_AO = 24576;        // bf16 [64][96]
-constexpr int L_OFF_T = 36864;         // 18 tiles bf16 [64][16]; later H bf16 [64][128], chunk ^ (row & 7) on the low 3 bits
-constexpr int L_OFF_BQ = 73728;        // fp32 [18][16]
-constexpr int L_OFF_TAB = 74880;       // fp32 [6][225]
-constexpr int L_LDS = 80280;
+constexpr int L_OFF_R1 = 0;            // 12 KB: Xn bf16 [64][64] (chunk ^ (row & 7)) in phases 0-1 and 4-5, ao bf16 [64][96] in phases 2-3
+constexpr int L_OFF_R2 = 12288;        // 36 KB: 18 head tiles bf16 [64][16] (1-2); E fp32 [64][64] (3-4); H bf16 [64][128] at +0 (5-6)
+constexpr int L_OFF_E2 = L_OFF_R2 + 16384;   //   and E2 fp32 [64][64] at +16 KB (6-7)
+constexpr int L_LDS = 49152;           // three workgroups per CU (LDS is granted in blocks: 54.5 KB with a bias table in LDS fitted only two)
 constexpr int L_TILE = 64 * 16;        // elements per head tile
 
 struct LightParams {
@@ -50,15 +54,14 @@ struct LightParams {
 
 __device__ __forceinline__ bf16x8_t zero8() { return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
 
-__global__ __launch_bounds__(512, 4) void swin_block_light_kernel(const LightParams p) {
+__global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* X = reinterpret_cast<float*>(smem + L_OFF_X);
-  bf16_t* Xn = reinterpret_cast<bf16_t*>(smem + L_OFF_XN);
-  bf16_t* AO = reinterpret_cast<bf16_t*>(smem + L_OFF_AO);
-  bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + L_OFF_T);
-  bf16_t* Hs = reinterpret_cast<bf16_t*>(smem + L_OFF_T);
-  float* bq = reinterpret_cast<float*>(smem + L_OFF_BQ);
-  float* tab = reinterpret_cast<float*>(smem + L_OFF_TAB);
+  bf16_t* Xn = reinterpret_cast<bf16_t*>(smem + L_OFF_R1);
+  bf16_t* AO = reinterpret_cast<bf16_t*>(smem + L_OFF_R1);
+  bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + L_OFF_R2);
+  float* E = reinterpret_cast<float*>(smem + L_OFF_R2);
+  bf16_t* Hs = reinterpret_cast<bf16_t*>(smem + L_OFF_R2);
+  float* E2 = reinterpret_cast<float*>(smem + L_OFF_E2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
@@ -67,191 +70,194 @@ __global__ __launch_bounds__(512, 4) void swin_block_light_kernel(const LightPar
   const float invC = 1.0f / (float)C;
 
   // ---- phase 0: gather + LayerNorm1 ----------------------------------------------------------------------------------
-  const int j4 = 4 * (tid & 15);                   // this thread's 4 channels; rows tid >> 4 and 32 + (tid >> 4)
-  int tok[2];
-  float4 xv[2];
+  const int j4 = 4 * (tid & 15), rr = tid >> 4;    // this thread: channels j4 .. j4 + 3 of rows rr + 16 i
+  int tok[4];
+  float4 xv[4];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    tok[h] = win_row_to_token(p.geom, (int)(b_ * 64) + 32 * h + (tid >> 4));
-    xv[h] = *reinterpret_cast<const float4*>(p.x + (long long)tok[h] * 64 + j4);
+  for (int i = 0; i < 4; ++i) {
+    tok[i] = win_row_to_token(p.geom, (int)(b_ * 64) + 16 * i + rr);
+    xv[i] = *reinterpret_cast<const float4*>(p.x + (long long)tok[i] * 64 + j4);
   }
-  // projection W slice of this wave: fragment f = which * 6 + head (first 16 columns of the head); waves 0, 1 own three
-  const int nfq = wave < 2 ? 3 : 2, fq0 = wave < 2 ? 3 * wave : 6 + 2 * (wave - 2);
-  bf16x8_t wq[3][2];
+  // projection W slice of this wave: fragment f = which * 6 + head (the first 16 columns of the head); 5 / 5 / 4 / 4
+  const int nfq = wave < 2 ? 5 : 4, fq0 = wave < 2 ? 5 * wave : 10 + 4 * (wave - 2);
+  bf16x8_t wq[5][2];
+  float4 bqv[5];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < 5; ++j) {
     const int f = fq0 + (j < nfq ? j : 0), which = f / 6, hh = f - 6 * which;
     const bf16_t* wr = p.Wqkv + (long long)(which * 192 + hh * 32 + r16) * 64;
 #pragma unroll
     for (int s = 0; s < 2; ++s) wq[j][s] = *reinterpret_cast<const bf16x8_t*>(wr + s * 32 + g * 8);
+    bqv[j] = p.bqkv ? *reinterpret_cast<const float4*>(p.bqkv + which * 192 + hh * 32 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int i = tid; i < 18 * 16; i += 512) {       // projection bias of the live fragments
-    const int f = i >> 4, which = f / 6, hh = f - 6 * which;
-    bq[i] = p.bqkv ? p.bqkv[which * 192 + hh * 32 + (i & 15)] : 0.f;
-  }
-  for (int i = tid; i < 6 * 225; i += 512) {       // rel-pos table out of the dense bias (as attn_fused.hip)
-    const int h = i / 225, t = i - h * 225;
-    const int dy = t / 15 - 7, dx = t - (t / 15) * 15 - 7;
-    const int qi = (dy > 0 ? dy : 0) * 8 + (dx > 0 ? dx : 0), kj = (dy < 0 ? -dy : 0) * 8 + (dx < 0 ? -dx : 0);
-    tab[i] = p.biasd[h * 4096 + qi * 64 + kj];
-  }
-  auto layer_norm = [&](const float4 (&v)[2], const float* gamma, const float* beta) {
+  auto layer_norm = [&](const float4 (&v)[4], const float* gamma, const float* beta) {
     const float4 gm = make_float4(j4 < C ? gamma[j4] : 0.f, j4 + 1 < C ? gamma[j4 + 1] : 0.f, j4 + 2 < C ? gamma[j4 + 2] : 0.f,
                                   j4 + 3 < C ? gamma[j4 + 3] : 0.f);
     const float4 bt = make_float4(j4 < C ? beta[j4] : 0.f, j4 + 1 < C ? beta[j4 + 1] : 0.f, j4 + 2 < C ? beta[j4 + 2] : 0.f,
                                   j4 + 3 < C ? beta[j4 + 3] : 0.f);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = 32 * h + (tid >> 4);
-      const float mean = wave_sum16((v[h].x + v[h].y) + (v[h].z + v[h].w)) * invC;      // pad columns are zero
-      const float d0 = j4 < C ? v[h].x - mean : 0.f, d1 = j4 + 1 < C ? v[h].y - mean : 0.f;
-      const float d2 = j4 + 2 < C ? v[h].z - mean : 0.f, d3 = j4 + 3 < C ? v[h].w - mean : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + rr;
+      const float mean = wave_sum16((v[i].x + v[i].y) + (v[i].z + v[i].w)) * invC;      // pad columns are zero
+      const float d0 = j4 < C ? v[i].x - mean : 0.f, d1 = j4 + 1 < C ? v[i].y - mean : 0.f;
+      const float d2 = j4 + 2 < C ? v[i].z - mean : 0.f, d3 = j4 + 3 < C ? v[i].w - mean : 0.f;
       const float rstd = rsqrtf(wave_sum16((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * invC + 1e-5f);
       *reinterpret_cast<uint2*>(Xn + swz_off(row, j4 >> 3) + (j4 & 4)) =
           pack_bf4(d0 * rstd * gm.x + bt.x, d1 * rstd * gm.y + bt.y, d2 * rstd * gm.z + bt.z, d3 * rstd * gm.w + bt.w);
     }
   };
-#pragma unroll
-  for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(X + (32 * h + (tid >> 4)) * 64 + j4) = xv[h];
   layer_norm(xv, p.n1w, p.n1b);
   srk_lds_barrier();
 
   // ---- phase 1: projection -> head tiles [f][64][16] ------------------------------------------------------------------
 #pragma unroll 1
   for (int mq = 0; mq < 4; ++mq) {
-    f32x4_t acc[3];
+    f32x4_t acc[5];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 5; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int row = 16 * mq + r16;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(Xn + swz_off(row, 4 * s + g));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[j][s], xf, acc[j], 0, 0, 0);
+      for (int j = 0; j < 5; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[j][s], xf, acc[j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 5; ++j) {
       if (j < nfq) {
         const int f = fq0 + j;
         const float sc = f < 6 ? p.scale : 1.0f;
-        const float4 bv = *reinterpret_cast<const float4*>(bq + 16 * f + 4 * g);
         *reinterpret_cast<uint2*>(tiles + f * L_TILE + row * 16 + 4 * g) =
-            pack_bf4((acc[j][0] + bv.x) * sc, (acc[j][1] + bv.y) * sc, (acc[j][2] + bv.z) * sc, (acc[j][3] + bv.w) * sc);
+            pack_bf4((acc[j][0] + bqv[j].x) * sc, (acc[j][1] + bqv[j].y) * sc, (acc[j][2] + bqv[j].z) * sc, (acc[j][3] + bqv[j].w) * sc);
       }
     }
   }
+  // proj W slice (phase 3): in flight under the attention.  This wave owns the token rows 16 wave .. in every GEMM below.
+  bf16x8_t wp[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)          // compact k = 32 s + 8 g + i -> head 2 s + (g >> 1), d = 8 (g & 1) + i
+      wp[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wproj + (long long)(16 * j + r16) * 192 + (2 * s + (g >> 1)) * 32 + 8 * (g & 1));
   srk_lds_barrier();
 
-  // ---- phase 2: attention, units u = wave + 8 k = 4 head + query tile -------------------------------------------------
+  // ---- phase 2: attention, query tile it = wave, heads 0..5 ---------------------------------------------------------------
   {
-    const int it = wave & 3, hw = wave >> 2;
-    const float* tabl = tab + ((2 * it + (r16 >> 3)) - (g >> 1) + 7) * 15 + ((r16 & 7) - 4 * (g & 1) + 7) - 93;
+    const int it = wave;
+    // rel-pos bias rows of this lane's query (dense [6][64][64], L2-resident): loaded one head ahead of their use
+    const float* bl = p.biasd + (16 * it + r16) * 64 + 4 * g;
+    auto load_bias = [&](f32x4_t (&bv)[4], int h) {
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float4 t4 = *reinterpret_cast<const float4*>(bl + h * 4096 + 16 * jt);
+        bv[jt] = f32x4_t{t4.x, t4.y, t4.z, t4.w};
+      }
+    };
     const int w = (int)(b_ % p.geom.nW);
     const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
     const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
     const int ll = lane & 15;
-#pragma unroll 1
-    for (int k = 0; k < 3; ++k) {
-      const int h = hw + 2 * k;
-      const bf16_t* Qs = tiles + (0 + h) * L_TILE;
-      const bf16_t* Ks = tiles + (6 + h) * L_TILE;
-      const bf16_t* Vs = tiles + (12 + h) * L_TILE;
-      // k = 8 g .. 8 g + 7 of the 32-deep MFMA: only d < 16 exists (lanes g >= 2 feed zeros)
-      const bf16x8_t qf = g < 2 ? *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * 16 + 8 * g) : zero8();
-      f32x4_t s[4];
+    auto units = [&](auto masked_c) {
+      f32x4_t bnext[4];
+      load_bias(bnext, 0);
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const bf16x8_t kf = g < 2 ? *reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * 16 + 8 * g) : zero8();
-        s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int h = 0; h < 6; ++h) {
+        const bf16_t* Qs = tiles + (0 + h) * L_TILE;
+        const bf16_t* Ks = tiles + (6 + h) * L_TILE;
+        const bf16_t* Vs = tiles + (12 + h) * L_TILE;
+        // k = 8 g .. 8 g + 7 of the 32-deep MFMA: only d < 16 exists (lanes g >= 2 feed zeros)
+        const bf16x8_t qf = g < 2 ? *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * 16 + 8 * g) : zero8();
+        f32x4_t s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const bf16x8_t kf = g < 2 ? *reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * 16 + 8 * g) : zero8();
+          s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) s[jt] += bnext[jt];
+        if (h < 5) load_bias(bnext, h + 1);
+        if constexpr (decltype(masked_c)::value) {
+          const int labi = win_region_label(p.geom, w, 16 * it + r16);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
+        }
+        bf16x8_t pf[2];
+        const float inv = softmax_numerators(s, pf);
+        f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {     // V^T fragment: rows d = 0..15, k = key in accumulator order (as tr_frag_acc)
+          const bf16x4_t lo = lds_tr_read(Vs + (32 * ss + 4 * g + (ll >> 2)) * 16 + ((ll & 3) << 2));
+          const bf16x4_t hi = lds_tr_read(Vs + (32 * ss + 16 + 4 * g + (ll >> 2)) * 16 + ((ll & 3) << 2));
+          const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ss], o, 0, 0, 0);
+        }
+        o *= inv;
+        // O[i = 16 it + r16][d = 4 g + e]; the ao tile lies on Xn, whose last readers (phase 1) are behind the barrier above
+        *reinterpret_cast<uint2*>(AO + (16 * it + r16) * 96 + h * 16 + 4 * g) = pack_bf4(o[0], o[1], o[2], o[3]);
       }
-      {
-        const float* th = tabl + h * 225;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) s[jt] += f32x4_t{th[93 - 30 * jt], th[92 - 30 * jt], th[91 - 30 * jt], th[90 - 30 * jt]};
-      }
-      if (masked) {
-        const int labi = win_region_label(p.geom, w, 16 * it + r16);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (win_region_label(p.geom, w, 16 * jt + 4 * g + e) != labi) s[jt][e] += -100.0f;   // :235 (-100, not -inf)
-      }
-      bf16x8_t pf[2];
-      const float inv = softmax_numerators(s, pf);
-      f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {     // V^T fragment: rows d = 0..15, k = key in accumulator order (as tr_frag_acc)
-        const bf16x4_t lo = lds_tr_read(Vs + (32 * ss + 4 * g + (ll >> 2)) * 16 + ((ll & 3) << 2));
-        const bf16x4_t hi = lds_tr_read(Vs + (32 * ss + 16 + 4 * g + (ll >> 2)) * 16 + ((ll & 3) << 2));
-        const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ss], o, 0, 0, 0);
-      }
-      o *= inv;
-      // o[e] = O[i = 16 it + r16][d = 4 g + e]
-      *reinterpret_cast<uint2*>(AO + (16 * it + r16) * 96 + h * 16 + 4 * g) = pack_bf4(o[0], o[1], o[2], o[3]);
-    }
+    };
+    if (masked) units(std::true_type{}); else units(std::false_type{});
   }
   srk_lds_barrier();
 
-  // ---- phase 3: proj over the compact K = 96 + bias + residual -> X ------------------------------------------------------
-  const int rt = wave & 3, cp = wave >> 2;         // this wave: rows 16 rt .., output columns 32 cp .. 32 cp + 31
+  // ---- phase 3: proj over the compact K = 96 -> E ---------------------------------------------------------------------------
+  const int row = 16 * wave + r16;         // this lane's token row in the GEMMs
   {
-    bf16x8_t wp[2][3];
+    f32x4_t acc[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int s = 0; s < 3; ++s)          // compact k = 32 s + 8 g + i -> head 2 s + (g >> 1), d = 8 (g & 1) + i
-        wp[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wproj + (long long)(32 * cp + 16 * j + r16) * 192 + (2 * s + (g >> 1)) * 32 + 8 * (g & 1));
-    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-    const int row = 16 * rt + r16;
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(AO + row * 96 + 32 * s + 8 * g);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[j][s], af, acc[j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[j][s], af, acc[j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {           // acc[j][e] = out[token row][n = 32 cp + 16 j + 4 g + e]
-      const int n = 32 * cp + 16 * j + 4 * g;
-      const float4 bv = p.bproj ? *reinterpret_cast<const float4*>(p.bproj + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4* xp = reinterpret_cast<float4*>(X + row * 64 + n);
-      const float4 xo = *xp;
-      *xp = make_float4(xo.x + acc[j][0] + bv.x, xo.y + acc[j][1] + bv.y, xo.z + acc[j][2] + bv.z, xo.w + acc[j][3] + bv.w);
-    }
+    for (int j = 0; j < 4; ++j)             // acc[j][e] = out[token row][n = 16 j + 4 g + e]
+      *reinterpret_cast<float4*>(E + row * 64 + 16 * j + 4 * g) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   }
+  // fc1 W slice (phase 5): in flight under phase 4
+  bf16x8_t w1[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) w1[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W1 + (long long)(16 * j + r16) * 64 + 32 * s + 8 * g);
   srk_lds_barrier();
 
-  // ---- phase 4: LayerNorm2 -> Xn ----------------------------------------------------------------------------------------
+  // ---- phase 4: x1 = x + proj + bias, LayerNorm2 -> Xn ------------------------------------------------------------------------
   {
-    float4 v[2];
+    const float4 bv = p.bproj ? *reinterpret_cast<const float4*>(p.bproj + j4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) v[h] = *reinterpret_cast<const float4*>(X + (32 * h + (tid >> 4)) * 64 + j4);
-    layer_norm(v, p.n2w, p.n2b);
+    for (int i = 0; i < 4; ++i) {
+      const float4 e = *reinterpret_cast<const float4*>(E + (16 * i + rr) * 64 + j4);
+      xv[i] = make_float4(xv[i].x + e.x + bv.x, xv[i].y + e.y + bv.y, xv[i].z + e.z + bv.z, xv[i].w + e.w + bv.w);
+    }
+    layer_norm(xv, p.n2w, p.n2b);
   }
   srk_lds_barrier();
 
   // ---- phase 5: fc1 + bias + GELU -> H [64][128] ----------------------------------------------------------------------
+  bf16x8_t w2[4][4];                        // fc2 W slice (phase 6): requested after the fc1 MFMAs, in flight under the GELU epilogue
   {
-    bf16x8_t w1[4][2];
+    f32x4_t acc[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        w1[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W1 + (long long)(64 * cp + 16 * j + r16) * 64 + 32 * s + 8 * g);
-    f32x4_t acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int row = 16 * rt + r16;
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(Xn + swz_off(row, 4 * s + g));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][s], xf, acc[j], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j][s], xf, acc[j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {           // hidden column n = 64 cp + 16 j + 4 g + e -> 16-byte chunk n >> 3 of the 256-byte row
-      const int n = 64 * cp + 16 * j + 4 * g;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) w2[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W2 + (long long)(16 * j + r16) * 128 + 32 * s + 8 * g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {           // hidden column n = 16 j + 4 g + e -> 16-byte chunk n >> 3 of the 256-byte row
+      const int n = 16 * j + 4 * g;
       const float4 bv = p.b1 ? *reinterpret_cast<const float4*>(p.b1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<uint2*>(Hs + row * 128 + (((n >> 3) ^ (row & 7)) << 3) + (n & 4)) =
           gelu_pack4(acc[j][0] + bv.x, acc[j][1] + bv.y, acc[j][2] + bv.z, acc[j][3] + bv.w);
@@ -259,39 +265,33 @@ __global__ __launch_bounds__(512, 4) void swin_block_light_kernel(const LightPar
   }
   srk_lds_barrier();
 
-  // ---- phase 6: fc2 + bias + residual -> X ------------------------------------------------------------------------------
+  // ---- phase 6: fc2 -> E2 ------------------------------------------------------------------------------------------------
   {
-    bf16x8_t w2[2][4];
+    f32x4_t acc[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        w2[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W2 + (long long)(32 * cp + 16 * j + r16) * 128 + 32 * s + 8 * g);
-    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-    const int row = 16 * rt + r16;
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8_t hf = *reinterpret_cast<const bf16x8_t*>(Hs + row * 128 + (((4 * s + g) ^ (row & 7)) << 3));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][s], hf, acc[j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][s], hf, acc[j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = 32 * cp + 16 * j + 4 * g;
-      const float4 bv = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4* xp = reinterpret_cast<float4*>(X + row * 64 + n);
-      const float4 xo = *xp;
-      *xp = make_float4(xo.x + acc[j][0] + bv.x, xo.y + acc[j][1] + bv.y, xo.z + acc[j][2] + bv.z, xo.w + acc[j][3] + bv.w);
-    }
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(E2 + row * 64 + 16 * j + 4 * g) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   }
   srk_lds_barrier();
 
-  // ---- phase 7: rows back to their tokens (window reverse + un-roll) ------------------------------------------------------
+  // ---- phase 7: x2 = x1 + fc2 + bias, rows back to their tokens (window reverse + un-roll) -------------------------------------
+  {
+    const float4 bv = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + j4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float4 v = *reinterpret_cast<const float4*>(X + (32 * h + (tid >> 4)) * 64 + j4);
-    *reinterpret_cast<float4*>(p.y + (long long)tok[h] * 64 + j4) = v;
-    if (p.yb) *reinterpret_cast<uint2*>(p.yb + (long long)tok[h] * 64 + j4) = pack_bf4(v.x, v.y, v.z, v.w);
+    for (int i = 0; i < 4; ++i) {
+      const float4 e = *reinterpret_cast<const float4*>(E2 + (16 * i + rr) * 64 + j4);
+      const float4 v = make_float4(xv[i].x + e.x + bv.x, xv[i].y + e.y + bv.y, xv[i].z + e.z + bv.z, xv[i].w + e.w + bv.w);
+      *reinterpret_cast<float4*>(p.y + (long long)tok[i] * 64 + j4) = v;
+      if (p.yb) *reinterpret_cast<uint2*>(p.yb + (long long)tok[i] * 64 + j4) = pack_bf4(v.x, v.y, v.z, v.w);
+    }
   }
 }
 
@@ -320,6 +320,6 @@ int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const floa
   LightParams p;
   p.x = x; p.y = y; p.yb = yb; p.n1w = n1w; p.n1b = n1b; p.n2w = n2w; p.n2b = n2b; p.Wqkv = Wqkv; p.Wproj = Wproj; p.W1 = W1; p.W2 = W2;
   p.bqkv = bqkv; p.bproj = bproj; p.b1 = b1; p.b2 = b2; p.biasd = biasd; p.scale = scale; p.C = C; p.B_ = B_; p.geom = geom;
-  hipLaunchKernelGGL(swin_block_light_kernel, dim3((unsigned)B_), dim3(512), L_LDS, stream, p);
+  hipLaunchKernelGGL(swin_block_light_kernel, dim3((unsigned)B_), dim3(256), L_LDS, stream, p);
   return srk_check_launch("swin_block_light");
 }
