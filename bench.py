@@ -137,7 +137,8 @@ INFER = {
     "cfg2": dict(metric="HR pixels/sec, SwinIR-light x2 inference, 48x48 LR, bs=16/GPU", batch=16, lr=48, scale=2, flop_per_image=4.818e9,
                  workload="BASELINE cfg2: SwinIR-light x2 (dim 60, 4x6 blocks, window 8, pixelshuffledirect) inference forward, 48x48 LR -> "
                           "96x96 HR, random-init weights",
-                 kernel="linear-layer GEMMs of the light model (gemm_kernel / gemm_stream*, csrc/gemm*.hip)"),
+                 kernel="swin_block_light_kernel (csrc/block_light.hip: one whole Swin block per launch, a window per workgroup) + the 3x3 conv "
+                        "implicit GEMMs (gemm_kernel, csrc/gemm.hip)"),
     "cfg4": dict(metric="HR pixels/sec, HAT x4 inference, 64x64 LR, bs=16/GPU", batch=16, lr=64, scale=4, flop_per_image=207.76e9,
                  workload="BASELINE cfg4: HAT-SRx4 (dim 180, 6x6 HAB + 6 OCAB, window 16, overlap 0.5, CAB) inference forward, 64x64 LR -> "
                           "256x256 HR, random-init weights",

@@ -216,6 +216,16 @@ int srk_gemm_ex(const srk_gemm_args* args, srk_stream_t stream);
 int srk_mlp_fused_fwd(const uint16_t* xn, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* res,
                       float* out, uint16_t* out_bf16, uint16_t* xn_next, float* xn_mean, float* xn_rstd, const float* xn_gamma,
                       const float* xn_beta, int xn_C, int M, srk_stream_t stream);
+/* SwinTransformerBlock.forward (network_swinir.py:239-279: LN1, roll + window partition, WindowAttention :114-145, reverse, residual,
+ * LN2, Mlp :25-28, residual) as ONE kernel at the SwinIR-light width (csrc/block_light.hip; inference, no DropPath).
+ * x, y: fp32 [B*H*W][64] token-major, channels >= C zero (y may alias x); y_bf16: optional bf16 copy of y.  Packed bf16 weights:
+ * wqkv [3*192][64] (row = which*192 + head*32 + d), wproj [64][192] (column = head*32 + d), w1 [128][64], w2 [64][128]; fp32
+ * biases in the same padded order; bias_dense [6][64][64] = table[rpi]; C <= 64, num_heads == 6, head_dim <= 16, hidden <= 128,
+ * H and W multiples of 8, shift 0 or 4.  SRK_E_UNSUPPORTED for any other width. */
+int srk_swin_block_fwd(const float* x, float* y, uint16_t* y_bf16, const float* norm1_w, const float* norm1_b, const float* norm2_w,
+                       const float* norm2_b, const uint16_t* wqkv, const float* bqkv, const uint16_t* wproj, const float* bproj,
+                       const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* bias_dense, float scale,
+                       int C, int num_heads, int head_dim, int hidden, int B, int H, int W, int shift, srk_stream_t stream);
 /* image -> padded, normalised NHWC4 (check_image_size + (x - mean) * range, hat_arch.py:963-975) and conv_first (fp32 VALU) */
 int srk_img_prep(const float* x, float* out, int B, int Cimg, int H0, int W0, int H, int W, float range, const float* mean3, srk_stream_t stream);
 int srk_stem_conv(const float* img4, const float* weight, const float* bias, float* out, int B, int H, int W, int Cin, int C, int CP,

@@ -305,7 +305,7 @@ void srk_block_light_enable(int on) { g_block_light = on ? 1 : 0; }
 int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const float* n1w, const float* n1b, const float* n2w, const float* n2b,
                                 const bf16_t* Wqkv, const bf16_t* Wproj, const bf16_t* W1, const bf16_t* W2, const float* bqkv,
                                 const float* bproj, const float* b1, const float* b2, const float* biasd, float scale, int C, int CP, int HP,
-                                int nH, int dh, long long B_, WinGeom geom, hipStream_t stream) {
+                                int nH, int dh, int HID, long long B_, WinGeom geom, hipStream_t stream) {
   if (!g_block_light || CP != 64 || HP != 128 || nH != 6 || dh > 16 || C > 64 || B_ < 1 || B_ >= (1LL << 24)) return SRK_NOT_COVERED;
   static int configured = 0;
   if (!configured) {
@@ -320,6 +320,13 @@ int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const floa
   LightParams p;
   p.x = x; p.y = y; p.yb = yb; p.n1w = n1w; p.n1b = n1b; p.n2w = n2w; p.n2b = n2b; p.Wqkv = Wqkv; p.Wproj = Wproj; p.W1 = W1; p.W2 = W2;
   p.bqkv = bqkv; p.bproj = bproj; p.b1 = b1; p.b2 = b2; p.biasd = biasd; p.scale = scale; p.C = C; p.B_ = B_; p.geom = geom;
+  // algorithmic (un-padded) work of one block: qkv + proj + MLP GEMMs and the two attention products; bytes: the residual stream
+  // in and out (+ the bf16 copy) and the weights once
+  const double T = 64.0 * (double)B_;
+  const double flops = T * (2.0 * 3 * C * C + 2.0 * C * C + 4.0 * C * HID + 4.0 * 64 * C);
+  const double bytes = T * C * (4.0 + 4.0 + (yb ? 2.0 : 0.0)) + 2.0 * (4.0 * C * C + 2.0 * C * HID);
+  srk_probe_pre(FAM_GEMM_LINEAR, stream, flops, bytes);
   hipLaunchKernelGGL(swin_block_light_kernel, dim3((unsigned)B_), dim3(256), L_LDS, stream, p);
+  srk_probe_post(FAM_GEMM_LINEAR, stream);
   return srk_check_launch("swin_block_light");
 }

@@ -184,6 +184,28 @@ int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* 
                                     (hipStream_t)stream);
 }
 
+int srk_swin_block_fwd(const float* x, float* y, uint16_t* y_bf16, const float* norm1_w, const float* norm1_b, const float* norm2_w,
+                       const float* norm2_b, const uint16_t* wqkv, const float* bqkv, const uint16_t* wproj, const float* bproj,
+                       const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* bias_dense, float scale,
+                       int C, int num_heads, int head_dim, int hidden, int B, int H, int W, int shift, srk_stream_t stream) {
+  SRK_REQUIRE(x && y && norm1_w && norm1_b && norm2_w && norm2_b && wqkv && wproj && w1 && w2 && bias_dense, SRK_E_NULL,
+              "swin_block_fwd: null operand");
+  SRK_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (shift == 0 || shift == 4), SRK_E_SHAPE,
+              "swin_block_fwd: B=%d H=%d W=%d shift=%d", B, H, W, shift);
+  SRK_REQUIRE(C > 0 && C <= 64 && hidden > 0 && hidden <= 128 && num_heads * head_dim == C, SRK_E_SHAPE,
+              "swin_block_fwd: C=%d heads=%d x %d hidden=%d", C, num_heads, head_dim, hidden);
+  WinGeom g;
+  g.H = H; g.W = W; g.nWw = W / 8; g.nW = (H / 8) * (W / 8); g.shift = shift;
+  const int rc = srk_launch_swin_block_light(x, y, y_bf16, norm1_w, norm1_b, norm2_w, norm2_b, wqkv, wproj, w1, w2, bqkv, bproj, b1, b2,
+                                             bias_dense, scale, C, 64, 128, num_heads, head_dim, hidden, (long long)B * g.nW, g,
+                                             (hipStream_t)stream);
+  if (rc == SRK_NOT_COVERED) {
+    srk_set_error("swin_block_fwd: only the light width (6 heads x d <= 16) has a whole-block kernel");
+    return SRK_E_UNSUPPORTED;
+  }
+  return rc;
+}
+
 // ---- generic GEMM / implicit-GEMM conv entry -----------------------------------------------------------------------------------
 int srk_gemm_ex(const srk_gemm_args* a, srk_stream_t stream) {
   SRK_REQUIRE(a != nullptr, SRK_E_NULL, "gemm_ex: null argument block");

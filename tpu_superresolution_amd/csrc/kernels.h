@@ -14,7 +14,7 @@ void srk_block_light_enable(int on);
 int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const float* n1w, const float* n1b, const float* n2w, const float* n2b,
                                 const bf16_t* Wqkv, const bf16_t* Wproj, const bf16_t* W1, const bf16_t* W2, const float* bqkv,
                                 const float* bproj, const float* b1, const float* b2, const float* biasd, float scale, int C, int CP, int HP,
-                                int nH, int dh, long long B_, WinGeom geom, hipStream_t stream);
+                                int nH, int dh, int HID, long long B_, WinGeom geom, hipStream_t stream);
 int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long long B_, int nH, WinGeom geom, hipStream_t stream);
 int srk_attn_bwd_slabs(long long B_, int nH, int* wpw_out);
 int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,

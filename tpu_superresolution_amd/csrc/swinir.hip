@@ -716,7 +716,7 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
             c.at<float>(ba.x_in), c.at<float>(ba.x_out), (j == depth - 1) ? c.at<bf16_t>(w.layer_xb[l]) : nullptr, params + bw.n1w,
             params + bw.n1b, params + bw.n2w, params + bw.n2b, c.packed + bw.Wqkv, c.packed + bw.Wproj, c.packed + bw.Wfc1,
             c.packed + bw.Wfc2, c.side + bw.bqkv, c.side + bw.bproj, c.side + bw.bfc1, c.side + bw.bfc2, c.side + bw.biasd, bw.scale, C,
-            CP, HP, bw.nH, bw.dh, T / 64, geom, st);
+            CP, HP, bw.nH, bw.dh, p->HID, T / 64, geom, st);
         if (rc_light != SRK_NOT_COVERED) {
           RUN(rc_light);
           ln1_done = false;
