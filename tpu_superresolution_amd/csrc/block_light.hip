@@ -17,7 +17,7 @@
 //   0  rows of the window gathered through the roll + window-partition map, LayerNorm1 -> Xn (bf16, swizzled)
 //   1  projection: 18 live 16-column fragments (q, k, v x 6 heads; 5 / 5 / 4 / 4 per wave), W in registers, + bias, q scaled
 //      -> head tiles [64][16]
-//   2  attention: 24 (head, 16-query tile) units, six per wave; K = 16 of the 32-deep MFMA (lanes k >= 16 feed zeros),
+//   2  attention: 24 (head, 16-query tile) units, six per wave; q k^T on the 16-deep MFMA (only 16 head columns are live),
 //      rel-pos bias rows from the dense table (L2, one head ahead), softmax_numerators, P.V on the 16 live columns -> ao [64][6 x 16]
 //   3  proj over the compact K = 96 -> exchange tile E
 //   4  x1 = x + E + bias (registers), LayerNorm2 -> Xn
@@ -29,6 +29,15 @@
 #include <type_traits>
 
 #include "kernels.h"
+
+#ifdef SRK_PROBE_LIGHT
+// developer instrumentation (never in the shipped build): s_memrealtime (100 MHz) at the phase boundaries of two workgroups
+__device__ unsigned long long g_light_probe[2 * 4 * 16];
+#define LIGHT_MARK(k) do { if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0) g_light_probe[((blockIdx.x ? 1 : 0) * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int srk_debug_light_probe(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_light_probe), sizeof(g_light_probe)); }
+#else
+#define LIGHT_MARK(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -52,8 +61,6 @@ struct LightParams {
   WinGeom geom;
 };
 
-__device__ __forceinline__ bf16x8_t zero8() { return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
-
 __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Xn = reinterpret_cast<bf16_t*>(smem + L_OFF_R1);
@@ -69,6 +76,7 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
   const int C = p.C;
   const float invC = 1.0f / (float)C;
 
+  LIGHT_MARK(0);
   // ---- phase 0: gather + LayerNorm1 ----------------------------------------------------------------------------------
   const int j4 = 4 * (tid & 15), rr = tid >> 4;    // this thread: channels j4 .. j4 + 3 of rows rr + 16 i
   int tok[4];
@@ -106,8 +114,11 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
           pack_bf4(d0 * rstd * gm.x + bt.x, d1 * rstd * gm.y + bt.y, d2 * rstd * gm.z + bt.z, d3 * rstd * gm.w + bt.w);
     }
   };
+  LIGHT_MARK(1);
   layer_norm(xv, p.n1w, p.n1b);
+  LIGHT_MARK(2);
   srk_lds_barrier();
+  LIGHT_MARK(3);
 
   // ---- phase 1: projection -> head tiles [f][64][16] ------------------------------------------------------------------
 #pragma unroll 1
@@ -139,7 +150,9 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
 #pragma unroll
     for (int s = 0; s < 3; ++s)          // compact k = 32 s + 8 g + i -> head 2 s + (g >> 1), d = 8 (g & 1) + i
       wp[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wproj + (long long)(16 * j + r16) * 192 + (2 * s + (g >> 1)) * 32 + 8 * (g & 1));
+  LIGHT_MARK(4);
   srk_lds_barrier();
+  LIGHT_MARK(5);
 
   // ---- phase 2: attention, query tile it = wave, heads 0..5 ---------------------------------------------------------------
   {
@@ -165,14 +178,13 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
         const bf16_t* Qs = tiles + (0 + h) * L_TILE;
         const bf16_t* Ks = tiles + (6 + h) * L_TILE;
         const bf16_t* Vs = tiles + (12 + h) * L_TILE;
-        // k = 8 g .. 8 g + 7 of the 32-deep MFMA: only d < 16 exists (lanes g >= 2 feed zeros)
-        const bf16x8_t qf = g < 2 ? *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * 16 + 8 * g) : zero8();
+        // q k^T over the 16 live head columns: the 16-deep MFMA (k = 4 g .. 4 g + 3 per lane), no zero padding to feed
+        const bf16x4_t qf = *reinterpret_cast<const bf16x4_t*>(Qs + (16 * it + r16) * 16 + 4 * g);
         f32x4_t s[4];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-          const bf16x8_t kf = g < 2 ? *reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * 16 + 8 * g) : zero8();
-          s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
+        for (int jt = 0; jt < 4; ++jt)
+          s[jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const bf16x4_t*>(Ks + (16 * jt + r16) * 16 + 4 * g), qf,
+                                                          f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) s[jt] += bnext[jt];
         if (h < 5) load_bias(bnext, h + 1);
@@ -201,7 +213,9 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
     };
     if (masked) units(std::true_type{}); else units(std::false_type{});
   }
+  LIGHT_MARK(6);
   srk_lds_barrier();
+  LIGHT_MARK(7);
 
   // ---- phase 3: proj over the compact K = 96 -> E ---------------------------------------------------------------------------
   const int row = 16 * wave + r16;         // this lane's token row in the GEMMs
@@ -225,7 +239,9 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int s = 0; s < 2; ++s) w1[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W1 + (long long)(16 * j + r16) * 64 + 32 * s + 8 * g);
+  LIGHT_MARK(8);
   srk_lds_barrier();
+  LIGHT_MARK(9);
 
   // ---- phase 4: x1 = x + proj + bias, LayerNorm2 -> Xn ------------------------------------------------------------------------
   {
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
     }
     layer_norm(xv, p.n2w, p.n2b);
   }
+  LIGHT_MARK(10);
   srk_lds_barrier();
 
   // ---- phase 5: fc1 + bias + GELU -> H [64][128] ----------------------------------------------------------------------
@@ -263,7 +280,9 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
           gelu_pack4(acc[j][0] + bv.x, acc[j][1] + bv.y, acc[j][2] + bv.z, acc[j][3] + bv.w);
     }
   }
+  LIGHT_MARK(11);
   srk_lds_barrier();
+  LIGHT_MARK(12);
 
   // ---- phase 6: fc2 -> E2 ------------------------------------------------------------------------------------------------
   {
@@ -280,6 +299,7 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(E2 + row * 64 + 16 * j + 4 * g) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   }
+  LIGHT_MARK(13);
   srk_lds_barrier();
 
   // ---- phase 7: x2 = x1 + fc2 + bias, rows back to their tokens (window reverse + un-roll) -------------------------------------
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
       if (p.yb) *reinterpret_cast<uint2*>(p.yb + (long long)tok[i] * 64 + j4) = pack_bf4(v.x, v.y, v.z, v.w);
     }
   }
+  LIGHT_MARK(14);
 }
 
 int g_block_light = 1;
