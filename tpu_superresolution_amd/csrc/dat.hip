@@ -27,74 +27,89 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
 }
 
-// threadIdx.x = 8-channel group, threadIdx.y = pixel lane; the thread keeps its group's 72 weights + scale / shift in registers and walks
+// threadIdx.x = 4-channel group, threadIdx.y = pixel lane; the thread keeps its group's 36 weights + scale / shift in registers and walks
 // DW_ITER consecutive pixels of one image row with a sliding 3 x 3 register window (a first version re-read weights and all nine
-// neighbours per pixel: 350 us per launch at cfg5, 53 % of the DAT forward).
-// w: fp32 [C8*8][9] (zero rows for pad channels), scale / shift: fp32 [C8*8]
+// neighbours per pixel: 350 us per launch at cfg5, 53 % of the DAT forward; eight channels per thread needed 188 VGPRs -- two waves
+// per SIMD under a chain of load -> unpack -> fma latencies, 63 us -- four need ~100).
+// w: fp32 [C4*4][9] (zero rows for pad channels), scale / shift: fp32 [C4*4]
 constexpr int DW_ITER = 8;
+__device__ __forceinline__ void unpack4(const uint2& v, float (&f)[4]) {
+  unpack_bf2(v.x, f[0], f[1]);
+  unpack_bf2(v.y, f[2], f[3]);
+}
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const bf16_t* __restrict__ mul, int ldm, bf16_t* __restrict__ out, int ldo, int B,
-                                                        int H, int W, int C8, int act) {
-  __shared__ float wsh[64 * 8 * 11];            // per channel: 9 taps, scale, shift (coalesced cooperative load, then registers)
+                                                        int H, int W, int C4, int act) {
+  __shared__ float wsh[128 * 4 * 11];           // per channel: 9 taps, scale, shift (coalesced cooperative load, then registers)
   const int nthr = blockDim.x * blockDim.y, lt = threadIdx.y * blockDim.x + threadIdx.x;
-  for (int i = lt; i < C8 * 8 * 9; i += nthr) wsh[(i / 9) * 11 + i % 9] = w[i];
-  for (int i = lt; i < C8 * 8; i += nthr) {
+  for (int i = lt; i < C4 * 4 * 9; i += nthr) wsh[(i / 9) * 11 + i % 9] = w[i];
+  for (int i = lt; i < C4 * 4; i += nthr) {
     wsh[i * 11 + 9] = scale[i];
     wsh[i * 11 + 10] = shift[i];
   }
   __syncthreads();
   const int cg = threadIdx.x;
-  float wr[9][8], sc[8], sh[8];
+  float wr[9][4], sc[4], sh[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 0; e < 4; ++e) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t][e] = wsh[(cg * 8 + e) * 11 + t];
-    sc[e] = wsh[(cg * 8 + e) * 11 + 9];
-    sh[e] = wsh[(cg * 8 + e) * 11 + 10];
+    for (int t = 0; t < 9; ++t) wr[t][e] = wsh[(cg * 4 + e) * 11 + t];
+    sc[e] = wsh[(cg * 4 + e) * 11 + 9];
+    sh[e] = wsh[(cg * 4 + e) * 11 + 10];
   }
   const long long npix = (long long)B * H * W;
   const long long p0 = ((long long)blockIdx.x * blockDim.y + threadIdx.y) * DW_ITER;
   if (p0 >= npix) return;
   // the thread's DW_ITER pixels lie in one image row (W % DW_ITER == 0, checked by the launcher): a 3 x 3 register window slides along
-  // x, so every step loads one new column (3 x 16 bytes) instead of nine pieces
+  // x, so every step loads one new column (3 x 8 bytes) instead of nine pieces
   const int x0 = (int)(p0 % W);
   const int y = (int)((p0 / W) % H);
-  float win[3][3][8];                       // [column slot][row dy + 1][channel]
-  auto load_col = [&](int slot, int xx) {
+  // every load of the segment is issued before the first use: (DW_ITER + 2) columns x 3 rows of 8 bytes (+ the gating operand) stay
+  // packed in registers; a load placed next to its use paid one memory round trip per pixel (2-3 us each, 87 us per launch)
+  uint2 raw[DW_ITER + 2][3], mraw[DW_ITER];
+#pragma unroll
+  for (int c = 0; c < DW_ITER + 2; ++c) {
+    const int xx = x0 + c - 1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int yy = y + r - 1;
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-        unpack8(*reinterpret_cast<const uint4*>(x + (p0 + (long long)(r - 1) * W + (xx - x0)) * ldx + cg * 8), win[slot][r]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) win[slot][r][e] = 0.f;
-      }
+      raw[c][r] = make_uint2(0u, 0u);
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        raw[c][r] = *reinterpret_cast<const uint2*>(x + (p0 + (long long)(r - 1) * W + (c - 1)) * ldx + cg * 4);
     }
+  }
+  if (mul) {
+#pragma unroll
+    for (int it = 0; it < DW_ITER; ++it) mraw[it] = *reinterpret_cast<const uint2*>(mul + (p0 + it) * ldm + cg * 4);
+  }
+  float win[3][3][4];                       // [column slot][row dy + 1][channel]
+  auto take_col = [&](int slot, int c) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) unpack4(raw[c][r], win[slot][r]);
   };
-  load_col(0, x0 - 1);
-  load_col(1, x0);
+  take_col(0, 0);
+  take_col(1, 1);
 #pragma unroll
   for (int it = 0; it < DW_ITER; ++it) {
     const long long pix = p0 + it;
-    load_col((it + 2) % 3, x0 + it + 1);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    take_col((it + 2) % 3, it + 2);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wr[r * 3 + dx][e], win[(it + dx) % 3][r][e], acc[e]);
-    float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (mul) unpack8(*reinterpret_cast<const uint4*>(mul + pix * ldm + cg * 8), m);
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(wr[r * 3 + dx][e], win[(it + dx) % 3][r][e], acc[e]);
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mul) unpack4(mraw[it], m);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 4; ++e) {
       float v = acc[e] * sc[e] + sh[e];
       if (act == 1) v = gelu_f(v);
       acc[e] = v * m[e];
     }
-    *reinterpret_cast<uint4*>(out + pix * ldo + cg * 8) = pack8(acc);
+    *reinterpret_cast<uint2*>(out + pix * ldo + cg * 4) = make_uint2(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]));
   }
 }
 
@@ -309,12 +324,13 @@ int srk_dwconv3x3(const uint16_t* x, int ldx, const float* w, const float* scale
               SRK_E_SHAPE, "dwconv3x3: bad shape / strides (16-byte pieces)");
   SRK_REQUIRE(C8 <= 64, SRK_E_SHAPE, "dwconv3x3: at most 512 channels (got %d)", 8 * C8);
   SRK_REQUIRE(W % DW_ITER == 0, SRK_E_UNSUPPORTED, "dwconv3x3: the image width must be a multiple of %d (got %d)", DW_ITER, W);
-  const int py = 256 / C8 < 1 ? 1 : 256 / C8;                          // pixel lanes per workgroup
+  const int C4 = 2 * C8;                                               // the kernel's threads own four channels each
+  const int py = 256 / C4 < 1 ? 1 : 256 / C4;                          // pixel lanes per workgroup
   const long long npix = (long long)B * H * W;
   const long long blocks = (npix + (long long)py * DW_ITER - 1) / ((long long)py * DW_ITER);
   SRK_REQUIRE(blocks < (1LL << 31), SRK_E_SHAPE, "dwconv3x3: too many pixels");
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(C8, py), 0, (hipStream_t)stream, x, ldx, w, scale, shift, mul, ldm, out, ldo, B,
-                     H, W, C8, act);
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(C4, py), 0, (hipStream_t)stream, x, ldx, w, scale, shift, mul, ldm, out, ldo, B,
+                     H, W, C4, act);
   return srk_check_launch("dwconv3x3");
 }
 
