@@ -169,18 +169,17 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void win256_attn_fwd_kernel
       mx = fmaxf(mx, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
     }
     mx = xrow_max4(mx);
-    float sum = 0.f;
+    constexpr float L2E = 1.4426950408889634f;      // exp(x - m) = exp2(x log2e - m log2e): one fma + v_exp_f32 per score (as softmax_numerators)
+    const float mxl = mx * L2E;
+    f32x4_t a4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      const f32x4_t t = s[j] * L2E - mxl;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pe = __expf(s[j][e] - mx);
-        s[j][e] = pe;
-        sum += pe;
-      }
+      for (int e = 0; e < 4; ++e) s[j][e] = __builtin_amdgcn_exp2f(t[e]);
+      a4 += s[j];
     }
-    sum = xrow_sum4(sum);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(xrow_sum4((a4[0] + a4[1]) + (a4[2] + a4[3])));
 
     // ---- O^T = V^T P^T ---------------------------------------------------------------------------------
     f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
