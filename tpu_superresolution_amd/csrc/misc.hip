@@ -336,6 +336,124 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
+// conv_first weight / bias gradient on the matrix cores.  dW[c][tap*4 + ci] = sum_pix gy[pix][c] * patch[pix][tap*4 + ci] is a
+// (C x 48) x pixels GEMM: per 32-pixel chunk the gy rows (fp32, split into bf16 hi + lo) and the im2col patch rows (36 values +
+// a column of ones that yields the bias gradient, hi + lo) are staged in LDS and read back as transposed fragments (k = pixel);
+// three MFMAs per product (hi.hi + hi.lo + lo.hi) keep ~16 mantissa bits, as accurate as the fp32 VALU kernel above for these
+// 131 072-term sums.  Every workgroup writes ONE partial [192][48] tile to the caller's scratch; stem_wgrad_reduce_kernel sums
+// them in a fixed order (the VALU kernel ended in 5 040 contended atomics per workgroup and took 203 us for 100 MB of input).
+constexpr int SW_GS = 200;                  // LDS row strides (elements): 192 + 8 and 48 + 8 keep the transposing reads conflict-free
+constexpr int SW_PS = 56;
+__device__ __forceinline__ bf16x8_t sw_frag(const bf16_t* tile, int stride, int c0, int lane) {   // T[k = 8 g + jj][c0 + r16]
+  const int g = lane >> 4;
+  const bf16x4_t lo = lds_tr_read(tr_addr(tile, stride, 8 * g, c0, lane)), hi = lds_tr_read(tr_addr(tile, stride, 8 * g + 4, c0, lane));
+  return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void sw_split4(float4 v, uint2& hi, uint2& lo) {
+  hi = pack_bf4(v.x, v.y, v.z, v.w);
+  float h0, h1, h2, h3;
+  unpack_bf2(hi.x, h0, h1);
+  unpack_bf2(hi.y, h2, h3);
+  lo = pack_bf4(v.x - h0, v.y - h1, v.z - h2, v.w - h3);
+}
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ in, const float* __restrict__ gy,
+                                                              float* __restrict__ partial, int B, int H, int W, int CP) {
+  __shared__ __attribute__((aligned(16))) bf16_t Gh[32 * SW_GS], Gl[32 * SW_GS], Ph[32 * SW_PS], Pl[32 * SW_PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const long long npix = (long long)B * H * W;
+  const int nchunk = (int)(npix / 32);
+  // patch columns 36..47: a one in column 36 (bias gradient), zeros elsewhere; written once
+  for (int i = tid; i < 32 * 12; i += 256) {
+    const int px = i / 12, c = 36 + i % 12;
+    Ph[px * SW_PS + c] = c == 36 ? (bf16_t)0x3F80 : (bf16_t)0;
+    Pl[px * SW_PS + c] = 0;
+  }
+  f32x4_t acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const long long p0 = (long long)ch * 32;
+    // gy rows: 32 x 192 fp32 = 1536 float4, six per thread
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = i * 256 + tid, px = q / 48, c4 = (q - px * 48) * 4;
+      uint2 hi, lo;
+      sw_split4(*reinterpret_cast<const float4*>(gy + (p0 + px) * CP + c4), hi, lo);
+      *reinterpret_cast<uint2*>(Gh + px * SW_GS + c4) = hi;
+      *reinterpret_cast<uint2*>(Gl + px * SW_GS + c4) = lo;
+    }
+    // patches: 32 pixels x 9 taps of one float4 (NHWC4 input), 288 pieces
+    for (int q = tid; q < 288; q += 256) {
+      const int px = q / 9, tap = q - px * 9;
+      const long long pix = p0 + px;
+      const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+      const long long b = pix / ((long long)W * H);
+      const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) v = *reinterpret_cast<const float4*>(in + ((b * H + yy) * W + xs) * 4);
+      uint2 hi, lo;
+      sw_split4(v, hi, lo);
+      *reinterpret_cast<uint2*>(Ph + px * SW_PS + tap * 4) = hi;
+      *reinterpret_cast<uint2*>(Pl + px * SW_PS + tap * 4) = lo;
+    }
+    __syncthreads();
+    bf16x8_t bh[3], bl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      bh[j] = sw_frag(Ph, SW_PS, 16 * j, lane);
+      bl[j] = sw_frag(Pl, SW_PS, 16 * j, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bf16x8_t ah = sw_frag(Gh, SW_GS, 16 * (3 * wave + i), lane), al = sw_frag(Gl, SW_GS, 16 * (3 * wave + i), lane);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // acc[i][j][e] = dW'[c = 16 (3 wave + i) + 4 g + e][n = 16 j + r16]
+  float* dst = partial + (size_t)blockIdx.x * (192 * 48);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(16 * (3 * wave + i) + 4 * g + e) * 48 + 16 * j + r16] = acc[i][j][e];
+}
+
+// dW[(c*Cin + ci)*9 + tap] += sum_w partial[w][c][tap*4 + ci], db[c] += sum_w partial[w][c][36]; one workgroup per channel c,
+// threads = 64 columns x 4 partial quarters, eight independent loads in flight
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nw, float* __restrict__ dW,
+                                                                float* __restrict__ db, int Cin) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x, n = threadIdx.x & 63, q = threadIdx.x >> 6;
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < 48) {
+    const float* base = partial + (size_t)c * 48 + n;
+    int w = q;
+    for (; w + 28 < nw; w += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += base[(size_t)(w + 4 * u) * (192 * 48)];
+    }
+    for (; w < nw; w += 4) a8[0] += base[(size_t)w * (192 * 48)];
+  }
+  part[q][n] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  __syncthreads();
+  if (q == 0 && n < 48) {
+    const float v = (part[0][n] + part[1][n]) + (part[2][n] + part[3][n]);
+    const int tap = n >> 2, ci = n & 3;
+    if (n < 36 && ci < Cin) dW[(c * Cin + ci) * 9 + tap] += v;
+    if (n == 36) db[c] += v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small-Cout convs (image heads: conv_last 64->3, light upsample C->r*r*3): gradients on the VALU
 // ------------------------------------------------------------------------------------------------
@@ -871,6 +989,15 @@ int srk_launch_stem_wgrad(const float* in, const float* gy, float* dW, float* db
                           int CP, hipStream_t stream) {
   SRK_REQUIRE(C <= 256 && Cin <= 4, SRK_E_SHAPE, "stem wgrad: C=%d > 256 or Cin=%d > 4 unsupported", C, Cin);
   const long long npix = (long long)B * H * W;
+  if (CP == 192 && npix % 32 == 0 && npix >= 32 * 512) {     // matrix-core kernel + fixed-order reduction through the caller's scratch
+    const int nw = 512;
+    float* scratch = srk_wgrad_scratch(stream, (size_t)nw * 192 * 48 * sizeof(float));
+    if (scratch) {
+      hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nw), dim3(256), 0, stream, in, gy, scratch, B, H, W, CP);
+      hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(C), dim3(256), 0, stream, scratch, nw, dW, db, Cin);
+      return srk_check_launch("stem_wgrad(mfma)");
+    }
+  }
   const int ppb = 512;       // measured at cfg3: 128 -> 468 us, 256 -> 258, 512 -> 200, 1024 -> 248 (the 5040 atomics per workgroup
                              // contend on the same 5040 addresses, so fewer, longer workgroups win until occupancy runs out)
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, stream, in, gy, dW, db, B,
