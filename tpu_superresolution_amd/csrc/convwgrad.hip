@@ -441,10 +441,14 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_mfma_kernel(const bf16_t*
   constexpr int YP = CT * COP / 4;          // float4 pieces of dY per chunk (64 or 256)
   float4 ry = make_float4(0.f, 0.f, 0.f, 0.f);
   uint4 rx[XPIECES];
+  // chunk -> (image, column block, row): consecutive chunks of a workgroup walk DOWN a CT-pixel column, so two of the three
+  // halo rows of a chunk were read by the previous one (a row-major walk re-read them W / CT chunks later, after they had left
+  // the L2: 0.79 GB of fetches per launch for a 268 MB input)
+  const int nxb = W / CT;
   auto load_stage = [&](int ch) {
-    const int m0 = ch * CT;
-    const int b = m0 / hw, rem = m0 - b * hw;
-    const int y = rem / W, x0 = rem - y * W;
+    const int b = ch / (H * nxb), r = ch - b * (H * nxb);
+    const int xb = r / H, y = r - xb * H, x0 = xb * CT;
+    const int m0 = b * hw + y * W + x0;
     if (tid < YP) ry = *reinterpret_cast<const float4*>(gy + (long long)m0 * COP + tid * 4);
 #pragma unroll
     for (int t = 0; t < XPIECES; ++t) {
