@@ -105,6 +105,8 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   "gemm_stream_bm" 0/16/32/64, "gemm_stream_ks2" -1/0/1, "gemm_stream_split" -1/0/1, "gemm_stream_nb" 0/4/8:
  *   tile-shape overrides of that kernel (0 / -1 = the measured per-epilogue defaults); used by tools/stream_sweep.py.
  *   "probe_stride" 1..1024: see srk_probe_begin.
+ *   "wgrad_stream_w8" 1 (default) / 0: the streaming weight-gradient kernel runs eight waves per workgroup (4 x 2 blocks of
+ *   48 x 96 of the 192 x 192 tile, two waves per SIMD) or four (2 x 2 blocks of 96 x 96); same sums in the same order.
  *   "block_light" 1 (default) / 0: SwinIR-light width (C <= 64, 6 heads x d <= 16, hidden <= 128), inference: each Swin block is
  *   ONE kernel (csrc/block_light.hip: LayerNorms, qkv, window attention, proj, MLP and both residuals of a window in LDS and
  *   registers) or the layer-per-launch path.

@@ -186,10 +186,12 @@ def test_streaming_linear_wgrad_vs_torch_and_register_staged_kernel(ops, M, N, K
     ref_w = y.float().t() @ x.float()
     ref_b = y.float().sum(0)
     out = {}
-    # (stream, rows per ring stage, nt loads, split partials via scratch + reduce kernel)
-    variants = {"ring32": (1, 32, 1, 1), "ring64": (1, 64, 0, 1), "ring32_atomics": (1, 32, 1, 0), "staged": (0, 32, 1, 1)}
+    # (stream, rows per ring stage, nt loads, split partials via scratch + reduce kernel, eight waves per workgroup)
+    variants = {"ring32": (1, 32, 1, 1, 1), "ring32_w4": (1, 32, 1, 1, 0), "ring64": (1, 64, 0, 1, 1), "ring64_w4": (1, 64, 0, 1, 0),
+                "ring32_atomics": (1, 32, 1, 0, 1), "ring32_atomics_w4": (1, 32, 1, 0, 0), "staged": (0, 32, 1, 1, 1)}
     try:
-        for name, (on, rows, nt, partials) in variants.items():
+        for name, (on, rows, nt, partials, w8) in variants.items():
+            check(lib().srk_set_option(b"wgrad_stream_w8", w8))
             check(lib().srk_set_option(b"wgrad_stream", on))
             check(lib().srk_set_option(b"wgrad_stream_rows", rows))
             check(lib().srk_set_option(b"wgrad_stream_nt", nt))
@@ -204,6 +206,8 @@ def test_streaming_linear_wgrad_vs_torch_and_register_staged_kernel(ops, M, N, K
         check(lib().srk_set_option(b"wgrad_stream_rows", 32))
         check(lib().srk_set_option(b"wgrad_stream_nt", 1))
         check(lib().srk_set_option(b"wgrad_partials", 1))
+        check(lib().srk_set_option(b"wgrad_stream_w8", 1))
+    assert torch.equal(out["ring32"][0], out["ring32_w4"][0])        # same per-element summation order in both wave shapes
     scale = max(1.0, float(ref_w.abs().max()))
     for name in variants:
         assert float((out[name][0] - ref_w).abs().max()) < 2e-3 * scale, name

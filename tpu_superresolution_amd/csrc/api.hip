@@ -253,6 +253,10 @@ int srk_set_option(const char* name, int value) {
     srk_attn_fused_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "wgrad_stream_w8") == 0) {
+    srk_wgrad_w8_enable(value);
+    return SRK_OK;
+  }
   if (strcmp(name, "block_light") == 0) {
     srk_block_light_enable(value);
     return SRK_OK;

@@ -33,6 +33,7 @@ struct WgradMulti {
   int tile_begin[5];    // prefix sum of tiles per problem
   float* partial;       // streaming kernels: scratch slabs [tile][split][WS_SLAB_VEC] of 4 floats, or null (atomics)
   int nsplit;
+  int w8;               // the slabs were written by the eight-wave shape of wgrad_stream_kernel (4 x 2 blocks of 48 x 96)
   RpbJob rpb;           // extra workgroups of wgrad_reduce_kernel (blockIdx >= 36 tiles), or slab == null
   WgradParams p[4];
 };
@@ -67,6 +68,7 @@ constexpr size_t WS_WORKSPACE_BYTES = (size_t)256 * WS_SLAB_VEC * 16;   // a lau
 float* srk_wgrad_scratch(hipStream_t stream, size_t bytes);   // the bound workspace if it is large enough, else null
 void srk_wgrad_bind_workspace(void* ptr, size_t bytes, void** prev_ptr, size_t* prev_bytes);
 void srk_wgrad_partials_enable(int on);
+void srk_wgrad_w8_enable(int on);
 void srk_wgrad_stream_tune(int rows, int nt);   // rows 32/64 (0 = keep), nt 0/1 (-1 = keep)
 int srk_wgrad_partials_enabled();
 

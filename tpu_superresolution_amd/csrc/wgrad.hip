@@ -201,8 +201,12 @@ __device__ __forceinline__ const bf16_t* tr_addr_swz(const bf16_t* tile, int rba
   return tile + row * 192 + (((c0 >> 4) ^ ((row >> 1) & 3)) << 4) + ((ll & 3) << 2);
 }
 
-template <int ROWS, bool NT>
-__global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) {
+// W8: eight waves (two per SIMD) share the 192 x 192 tile as 4 x 2 blocks of 48 x 96 instead of four waves with 96 x 96 each:
+// with one wave per SIMD nothing covers that wave's own LDS reads, DMA issue and waits (MFMA pipe 32 % busy, 40 % issue stalls);
+// waves 0..3 still issue the whole DMA ring.
+template <int ROWS, bool NT, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256) void wgrad_stream_kernel(const WgradMulti mp) {
+  constexpr int FI = W8 ? 3 : 6;                       // 16-row n-fragments per wave
   constexpr int STAGE_ELEMS = 2 * ROWS * 192;          // Y chunk + X chunk, bf16 elements
   constexpr int RING = WS_LDS_BYTES / (STAGE_ELEMS * 2);
   constexpr int NI = ROWS * 24 / 256;                  // DMA instructions per wave, chunk and operand (6 or 3)
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave >> 1, wk = wave & 1;             // n block (16 FI rows), k half (96 columns)
+  const bool loader = wave < 4;                        // the DMA ring is issued by four waves in either shape
   const int ntn = p.N / 192;
   const int bx = btile - mp.tile_begin[pi];
   const int tn = bx % ntn, tk = bx / ntn;
@@ -236,13 +241,14 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
   int yoff[NI], xoff[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int q = wave * (NI * 64) + i * 64 + lane;
+    const int q = (wave & 3) * (NI * 64) + i * 64 + lane;
     const int row = q / 24, pos = q - row * 24;
     const int c = (((pos >> 1) ^ ((row >> 1) & 3)) << 1) | (pos & 1);
     yoff[i] = row * p.ldy + n0 + c * 8;
     xoff[i] = row * p.ldx + k0 + c * 8;
   }
   auto issue = [&](int ch) {
+    if (!loader) return;
     const int m0 = m_begin + ch * ROWS;
     const bf16_t* yb = p.Y + (long long)m0 * p.ldy;
     const bf16_t* xb = p.X + (long long)m0 * p.ldx;
@@ -255,9 +261,9 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
       srk_glds16<NT>(xb + xoff[i], __builtin_amdgcn_readfirstlane(dst + ROWS * 192 * 2 + (wave * (NI * 64) + i * 64) * 16));
   };
 
-  f32x4_t acc[6][6], accb[6];
+  f32x4_t acc[FI][6], accb[FI];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < FI; ++i) {
     accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -279,10 +285,10 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
     const bf16_t* xs = ys + ROWS * 192;
 #pragma unroll
     for (int ks = 0; ks < ROWS / 32; ++ks) {
-      bf16x8_t yf[6], xf[6];
+      bf16x8_t yf[FI], xf[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int c0 = wn * 96 + 16 * i;
+      for (int i = 0; i < FI; ++i) {
+        const int c0 = wn * (16 * FI) + 16 * i;
         const bf16x4_t lo = lds_tr_read(tr_addr_swz(ys, 32 * ks + 4 * g, c0, lane));
         const bf16x4_t hi = lds_tr_read(tr_addr_swz(ys, 32 * ks + 16 + 4 * g, c0, lane));
         yf[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -295,12 +301,12 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
         xf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
       if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < FI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
       }
     }
   }
@@ -309,15 +315,15 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const WgradMulti mp) 
     // partial tile in accumulator order ([wave][i][j][lane] x 4 floats: every store instruction writes 1 KiB
     // contiguous); wgrad_reduce_kernel sums the splits.  Float atomics of this shape (4 x 64-B segments per
     // instruction, 9.4 M of them per launch) cost ~60 us per launch.
-    f32x4_t* slab = reinterpret_cast<f32x4_t*>(mp.partial) + (((size_t)btile * 144 + wave * 36) * mp.nsplit + bsplit) * 64 + lane;
+    f32x4_t* slab = reinterpret_cast<f32x4_t*>(mp.partial) + (((size_t)btile * 144 + wave * (FI * 6)) * mp.nsplit + bsplit) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
       for (int j = 0; j < 6; ++j) slab[(size_t)(i * 6 + j) * mp.nsplit * 64] = acc[i][j];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int n = n0 + wn * 96 + 16 * i + 4 * g;
+  for (int i = 0; i < FI; ++i) {
+    const int n = n0 + wn * (16 * FI) + 16 * i + 4 * g;
     if (mp.partial == nullptr) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -362,9 +368,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradMulti mp) 
   }
   for (; s < mp.nsplit; ++s) sum += src[s * 64];
   const int lane = q & 63, t = q >> 6;
-  const int j = t % 6, i = (t / 6) % 6, wave = t / 36;
+  const int fi = mp.w8 ? 3 : 6;                                  // n-fragments per wave of the kernel that wrote the slabs
+  const int j = t % 6, i = (t / 6) % fi, wave = t / (6 * fi);
   const int wn = wave >> 1, wk = wave & 1, r16 = lane & 15, g = lane >> 4;
-  const int n = tn * 192 + wn * 96 + 16 * i + 4 * g;
+  const int n = tn * 192 + wn * (16 * fi) + 16 * i + 4 * g;
   const int k = tk * 192 + wk * 96 + 16 * j + r16;
 #pragma unroll
   for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + k, sum[e]);
@@ -376,6 +383,10 @@ thread_local bool t_rpb_done = false;
 int g_wgrad_stream = 1;
 int g_wgrad_rows = 32;      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
 int g_wgrad_nt = 1;         // nt (streaming) cache policy on its operand DMAs
+#ifndef SRK_WGRAD_W8_DEFAULT
+#define SRK_WGRAD_W8_DEFAULT 1
+#endif
+int g_wgrad_w8 = SRK_WGRAD_W8_DEFAULT;   // eight waves per workgroup (two per SIMD) in the streaming kernel
 int g_wgrad_partials = 1;   // split partials to scratch slabs + reduce kernel (1) or fp32 atomics straight into dW (0)
 
 template <int TA, int TB, bool CONV>
@@ -395,6 +406,7 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   mp.partial = nullptr;
   mp.nsplit = 0;
   mp.rpb = RpbJob{nullptr, nullptr, 0, 0};
+  mp.w8 = 0;
   int tiles = 0;
   double flops = 0.0, bytes = 0.0;
   for (int i = 0; i < nprob; ++i) {
@@ -420,8 +432,10 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
     if (ok) {
       constexpr int slds = WS_LDS_BYTES;
       using KernelFn = void (*)(const WgradMulti);
-      static const KernelFn fns[4] = {&wgrad_stream_kernel<64, false>, &wgrad_stream_kernel<64, true>, &wgrad_stream_kernel<32, false>,
-                                      &wgrad_stream_kernel<32, true>};
+      static const KernelFn fns[8] = {&wgrad_stream_kernel<64, false, false>, &wgrad_stream_kernel<64, true, false>,
+                                      &wgrad_stream_kernel<32, false, false>, &wgrad_stream_kernel<32, true, false>,
+                                      &wgrad_stream_kernel<64, false, true>,  &wgrad_stream_kernel<64, true, true>,
+                                      &wgrad_stream_kernel<32, false, true>,  &wgrad_stream_kernel<32, true, true>};
       static bool sconf = false;
       if (!sconf) {
         for (KernelFn f : fns)
@@ -431,11 +445,12 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
           }
         sconf = true;
       }
-      const KernelFn fn = fns[(g_wgrad_rows == 32 ? 2 : 0) + (g_wgrad_nt ? 1 : 0)];
+      const KernelFn fn = fns[(g_wgrad_w8 ? 4 : 0) + (g_wgrad_rows == 32 ? 2 : 0) + (g_wgrad_nt ? 1 : 0)];
       mp.nsplit = splits;
+      mp.w8 = g_wgrad_w8;
       mp.partial = g_wgrad_partials && splits > 1 ? srk_wgrad_scratch(stream, (size_t)tiles * splits * WS_SLAB_VEC * 16) : nullptr;
       srk_probe_pre(fam, stream, flops, bytes);
-      hipLaunchKernelGGL(fn, dim3(tiles * splits), dim3(256), slds, stream, mp);
+      hipLaunchKernelGGL(fn, dim3(tiles * splits), dim3(g_wgrad_w8 ? 512 : 256), slds, stream, mp);
       if (mp.partial) {
         int extra = 0;
         if (t_rpb && t_rpb->slab) {
@@ -486,6 +501,7 @@ int validate(const WgradParams& p) {
 
 void srk_wgrad_stream_enable(int on) { g_wgrad_stream = on ? 1 : 0; }
 void srk_wgrad_partials_enable(int on) { g_wgrad_partials = on ? 1 : 0; }
+void srk_wgrad_w8_enable(int on) { g_wgrad_w8 = on ? 1 : 0; }
 void srk_wgrad_stream_tune(int rows, int nt) {
   if (rows == 32 || rows == 64) g_wgrad_rows = rows;
   if (nt >= 0) g_wgrad_nt = nt ? 1 : 0;
