@@ -105,8 +105,29 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
     }
   }
 
+#ifndef SRK_ROWEP_EARLY_RES
+#define SRK_ROWEP_EARLY_RES 1
+#endif
+  // EP_RES (the 3x3 convs of the RSTBs): the residual rows of a half are requested BEFORE its accumulators go through LDS, so that
+  // their round trip runs under the tile write, the barrier and the LayerNorm of the rows ahead instead of in a per-row
+  // load -> use -> store chain
+  constexpr bool EARLY = SRK_ROWEP_EARLY_RES != 0 && (EP == EP_RES || EP == EP_RES_BF16);
+  float4 er[EARLY ? 4 : 1][NC];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int lr = wave * 16 + u * 4 + sub;
+        const int m = m0 + (lr >> 5) * 64 + half * 32 + (lr & 31);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int n = n0 + 64 * c + 4 * j16;
+          er[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < p.M && n < p.N) er[u][c] = *reinterpret_cast<const float4*>(p.res + (long long)m * p.ldo + n);
+        }
+      }
+    }
     if (half) srk_lds_barrier();      // LDS hazard only: a __syncthreads() would also wait for the first half's global stores
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -142,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           if constexpr (EP == EP_PROJ_RES) {
             pf_a[u][c] = *reinterpret_cast<const float4*>(p.res + (long long)win_row_to_token(p.geom, m) * p.ldo + n);
           } else if constexpr (EP == EP_RES || EP == EP_RES_BF16) {
-            pf_a[u][c] = *reinterpret_cast<const float4*>(p.res + (long long)m * p.ldo + n);
+            if constexpr (!EARLY) pf_a[u][c] = *reinterpret_cast<const float4*>(p.res + (long long)m * p.ldo + n);
           } else if constexpr (EP == EP_DGELU || EP == EP_DLRELU) {
             pf_u[u][c] = *reinterpret_cast<const uint2*>(p.aux + (long long)m * p.ldo + n);
           } else if constexpr (EP == EP_LNBWD) {
@@ -230,7 +251,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           const int n = n0 + 64 * c + 4 * j16;
           o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (n >= p.N) continue;
-          const float4 rv = pf_a[u][c];
+          float4 rv;
+          if constexpr (EARLY) rv = er[it][c]; else rv = pf_a[u][c];
           o[c] = make_float4(rv.x + v[c].x * f, rv.y + v[c].y * f, rv.z + v[c].z * f, rv.w + v[c].w * f);
           if constexpr (EP == EP_RES) *reinterpret_cast<float4*>(p.outf + (long long)m * p.ldo + n) = o[c];
           if (EP == EP_RES_BF16 || p.outb)
