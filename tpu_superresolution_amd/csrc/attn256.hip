@@ -63,6 +63,17 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void win256_attn_fwd_kernel
   const int wy = w / p.nWw, wx = w - wy * p.nWw;
   const long long tok0 = (long long)b * p.H * p.W;
 
+  // query fragment of a 16-query tile: requested one tile ahead (the first one before the K / V staging), so that its round trip
+  // runs under the previous tile's work instead of in front of every tile's dependent chain
+  auto load_q = [&](int qt) {
+    const int ql = wave * 64 + qt * 16 + r16;
+    const int qy = ql / p.ww, qx = ql - qy * p.ww;
+    int y = wy * p.wh + qy + p.sy, x = wx * p.ww + qx + p.sx;
+    if (y >= p.H) y -= p.H;
+    if (x >= p.W) x -= p.W;
+    return *reinterpret_cast<const bf16x8_t*>(p.qkv + (tok0 + (long long)y * p.W + x) * p.ldq + h * 32 + 8 * g);
+  };
+  bf16x8_t qf_next = load_q(0);
   // ---- stage K, V of the window -------------------------------------------------------------------
   for (int kk = tid; kk < NK; kk += 256) {
     const int ky = kk / p.kw, kx = kk - ky * p.kw;
@@ -106,7 +117,10 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void win256_attn_fwd_kernel
   // interior windows of a shifted map have one region label throughout: only the last window row / column is masked
   const bool need_mask = masked && (wy == p.nWh - 1 || wx == p.nWw - 1);
 
-#pragma unroll 1
+  // 16 key tiles: the four query tiles are unrolled -- without a loop the compiler does not hoist the per-tile LDS addresses into
+  // registers (236 -> ~150 VGPRs), which lets a third workgroup share the CU; 36 key tiles (overlapping windows) stay rolled
+  constexpr int QT_UNROLL = NT <= 16 ? 4 : 1;
+#pragma unroll QT_UNROLL
   for (int qt = 0; qt < 4; ++qt) {
     // this lane's query: window-local index, raster token, region label
     const int ql = wave * 64 + qt * 16 + r16;
@@ -116,7 +130,8 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void win256_attn_fwd_kernel
     if (x >= p.W) x -= p.W;
     const long long qtok = tok0 + (long long)y * p.W + x;
     const int qlab = need_mask ? region_label(wy * p.wh + qy, p.H, p.wh, p.sy) * 3 + region_label(wx * p.ww + qx, p.W, p.ww, p.sx) : 0;
-    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(p.qkv + qtok * p.ldq + h * 32 + 8 * g);
+    const bf16x8_t qf = qf_next;
+    if (qt < 3) qf_next = load_q(qt + 1);
 
     // ---- S^T tiles -----------------------------------------------------------------------------------
     f32x4_t s[NT];
