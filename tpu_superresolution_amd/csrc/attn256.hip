@@ -47,7 +47,7 @@ __device__ __forceinline__ int region_label(int v, int n, int w, int s) { return
 // rpi_oca[p][k] = (yk - yp + ws - wse + 1)(ws + wse - 1) + (xk - xp + ws - wse + 1), wrapped by the table length when negative
 // (:896-918 + torch's negative indexing) -- instead of streaming a dense [256][NK] fp32 slab per workgroup from L2.
 template <int NT, bool OCA, bool TABLE>        // NT = key tiles of 16 (16: 256 keys, 36: 576 keys)
-__global__ __launch_bounds__(256, (NT > 16 ? 1 : 2)) void win256_attn_fwd_kernel(const Win256Params p) {
+__global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel(const Win256Params p) {
   constexpr int NK = NT * 16;
   constexpr int KW = OCA ? 24 : 16;                      // key-window width in table mode (16 x 16 / 24 x 24 windows)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
