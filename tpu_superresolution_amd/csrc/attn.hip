@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 //   phase 2  wave w = key tile jt:   dV^T[:, jt], dK^T[:, jt] (sum over all 64 queries) and dQ^T[:, it = w]
 // 160 VGPRs per wave and 38 KB of LDS per workgroup -> 3 workgroups (12 waves) per CU hide each other's
 // latencies; the next window's q/k/v/dO tiles are prefetched into registers during phase 2.
-__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
+#ifndef SRK_ATTN_BWD_WGS
+#define SRK_ATTN_BWD_WGS 3
+#endif
+__global__ __launch_bounds__(256, SRK_ATTN_BWD_WGS) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ biasd,
                                                        const bf16_t* __restrict__ dao, bf16_t* __restrict__ dqkv,
                                                        float* __restrict__ dbias_slab, long long B_, int nH, int CA,
                                                        WinGeom geom, int wpw, float scale) {
@@ -416,7 +419,7 @@ int srk_launch_attn_fwd(const bf16_t* qkv, const float* biasd, bf16_t* ao, long 
 
 int srk_attn_bwd_slabs(long long B_, int nH, int* wpw_out) {
   // windows per workgroup: as few as possible while all workgroups are resident at once (3 per CU: 160 VGPRs)
-  const long long slots = 3 * 256;
+  const long long slots = SRK_ATTN_BWD_WGS * 256;
   long long wpw = (B_ * nH + slots - 1) / slots;
   if (wpw < 1) wpw = 1;
   while (((B_ + wpw - 1) / wpw) * nH > slots && wpw < B_) ++wpw;
