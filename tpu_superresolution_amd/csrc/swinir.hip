@@ -1196,7 +1196,9 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           g.ldo = CP; g.flops = fl_qkv;
           g.bytes = (double)T * (6.0 * C + 4.0 * C + 8.0 * C + 2.0 * C) + 6.0 * C * C;   // d qkv, x, gx in; gx, gxb2 out
           if (fuse_ln) {   // ... with LN1 backward (+ window reverse + un-roll) fused: gx2[tok] += dx, gxb2 = bf16(gx2 * f_mlp(prev))
-            g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxb2); g.geom = geom; g.rowscale = ds_prev_mlp; g.rows_per_sample = HW;
+            // the bf16 copy feeds the previous block's fc2 gradients; behind the first block of the layer nobody reads it (the RSTB skip
+            // add below produces the layer's bf16 gradient)
+            g.outf = c.at<float>(w.gx2); g.outb = j > 0 ? c.at<bf16_t>(w.gxb2) : nullptr; g.geom = geom; g.rowscale = ds_prev_mlp; g.rows_per_sample = HW;
             g.ln_x = c.at<float>(ba.x_in); g.ln_mean = c.at<float>(ba.mean1); g.ln_rstd = c.at<float>(ba.rstd1);
             g.ln_gamma = params + bw.n1w; g.ln_dgamma = grads + bw.n1w; g.ln_dbeta = grads + bw.n1b; g.ln_C = C;
             g.ln_rows_window = 1; g.ln_stats_by_m = 1; g.ln_out_window = 0;
