@@ -40,6 +40,8 @@ HR_PX_PER_SAMPLE = 256 * 256
 FLOP_PER_IMAGE_TRAIN = 321.299e9      # fwd+bwd algorithmic FLOPs per 64x64 LR image
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 PROBE_STRIDE = 5
+FAMILY_TRAFFIC_FILE = "r03_pmc_linear_gemm_stream_traffic.json"     # rocprofv3 PMC summaries this round's library was measured with
+STEP_TRAFFIC_FILE = "r03_pmc_step_traffic.json"
 HBM_PEAK_GBS = 8000.0                # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy ceiling)
 
 
@@ -49,6 +51,27 @@ def synthetic_batch(batch, device, seed):
     hr = torch.nn.functional.interpolate(lr, scale_factor=4, mode="bicubic", align_corners=False)
     hr = (hr + 0.02 * torch.rand(hr.shape, generator=torch.Generator().manual_seed(seed + 1))).clamp(0, 1)
     return lr.to(device), hr.to(device)
+
+
+def psnr_delta(model, batch=2):
+    """BASELINE's quality gate ("PSNR delta vs ref <= 0.01 dB"): the HIP forward and the CPU oracle's fp32 forward of the SAME
+    weights (the benchmarked model's state_dict as it stands after the timed steps) on the SURVEY 8d synthetic target."""
+    from oracle import swinir_oracle as O
+    cfg = O.SwinIRConfig.classical_x4()
+    lr, hr = O.synthetic_batch(batch, 64, 4, seed=0)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        y_hip = model(lr.to(next(model.parameters()).device)).float().cpu()
+        y_ref = O.swinir_forward(sd, cfg, lr)
+    model.train(was_training)
+    p_hip, p_ref = float(O.batch_psnr(y_hip, hr).mean()), float(O.batch_psnr(y_ref, hr).mean())
+    mse = float(((y_hip - y_ref) ** 2).mean())
+    return {"psnr_delta_db": p_hip - p_ref, "psnr_hip_db": p_hip, "psnr_oracle_db": p_ref,
+            "max_abs_diff": float((y_hip - y_ref).abs().max()),
+            "mutual_psnr_db": float(10.0 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20)))),
+            "sample": f"eval forward of the benchmarked weights, batch {batch}, 64x64 LR -> 256x256 HR, HIP bf16 path vs CPU oracle fp32"}
 
 
 def cpu_baseline(steps=3, batch=2, threads=None):
@@ -302,13 +325,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="developer A/B: srk_set_option(NAME, VALUE) before the model is built (repeatable)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"cfg3": 20, "cfg2": 200, "cfg4": 10, "cfg5": 10}[args.config]
+        args.steps = {"cfg3": 50, "cfg2": 200, "cfg4": 10, "cfg5": 10}[args.config]     # >= 50 steps, median reported beside
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])           # never returns
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    for item in args.opt:
+        from tpu_superresolution_amd import _lib as _l
+        name, _, value = item.partition("=")
+        _l.check(_l.lib().srk_set_option(name.encode(), int(value)))
     if args.config in INFER:
         return bench_inference(args)
     args.batch = args.batch or 32
@@ -334,6 +363,8 @@ def main():
     torch.manual_seed(1234 + rank)                         # DropPath stream differs per rank
     lr_img, hr_img = synthetic_batch(args.batch, device, seed=1000 + rank)
     sync = dp if world > 1 else None
+    if world > 1 and dp._sync is not None:
+        dp._sync.time_exposed = True
 
     def barrier():
         if world > 1:
@@ -352,11 +383,21 @@ def main():
         # sample is uniform over the kernels; bracketing every launch costs ~4 % of the step in event records.
         _lib.check(lib.srk_set_option(b"probe_stride", PROBE_STRIDE))
         _lib.check(lib.srk_probe_begin(1, 400 * args.steps))
+    if world > 1 and dp._sync is not None:
+        dp._sync.exposed_ms()                              # drop the warm-up steps' samples
+    # `ms_per_step` / `value` come from the wall clock around EXACTLY args.steps steps (driver contract); an event per step
+    # boundary on the compute stream gives the per-step durations the median is taken from
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss, bad = train_step(model, opt, lr_img, hr_img, sync)
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
+    exposed = dp._sync.exposed_ms() if (world > 1 and dp._sync is not None) else None
     roof = None
     if probe:
         ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
@@ -366,11 +407,12 @@ def main():
             # MI355X ridge (~310 FLOP/B), so with one launch per layer the family is HBM-bound, not MFMA-bound.
             gbs = by.value / (ms.value * 1e-3) / 1e9
             tfl = fl.value / (ms.value * 1e-3) / 1e12
-            fam, fam_src = stored_traffic("r02_pmc_linear_gemm_stream_traffic.json")
+            fam, fam_src = stored_traffic(FAMILY_TRAFFIC_FILE)
             traffic = fam["avg_hbm_bytes_per_launch"] if fam and fam_src["matches_this_library"] else None
-            roof = {"bound": "hbm", "kernel": "gemm_stream_kernel / gemm_stream_split_kernel (csrc/gemm_stream.hip: persistent LDS-DMA "
-                                               "GEMM of the linear layers -- proj/fc1/fc2 forward and the qkv/proj/fc1/fc2 dgrads with their "
-                                               "fused bias/GELU/residual/LayerNorm epilogues; the qkv forward lives in attn_fused.hip)",
+            roof = {"bound": "hbm", "kernel": "gemm_stream_kernel / gemm_stream_split_kernel / mlp_fused_fwd_kernel (csrc/gemm_stream.hip: "
+                                               "persistent LDS-DMA GEMMs of the linear layers -- proj and the fused fc1+GELU+fc2 forward, the "
+                                               "fc2 / fc1 / qkv dgrads with their fused bias/GELU'/residual/LayerNorm(-backward) epilogues; the "
+                                               "qkv forward lives in attn_fused.hip, the proj dgrad in attn_bwd_fused.hip)",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": fam_src,
                     "algorithmic_bytes_per_launch": by.value / n.value, "launches": n.value, "sampled_every": PROBE_STRIDE,
@@ -394,21 +436,46 @@ def main():
                                       "+ clip 1.0 + AdamW, 64x64 LR patches -> 256x256 HR, random-init weights, drop_path 0.1",
                           "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                           "per_gpu_value": value / world,
+                          "ms_per_step_median": median_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
+                          "timing": "value / ms_per_step: wall clock around the K steps between two barrier + synchronize pairs; "
+                                    "median / min / max: HIP events at the step boundaries on the compute stream (rank 0)",
                           "step_tflops_per_gpu": args.batch * FLOP_PER_IMAGE_TRAIN / (ms_per_step * 1e-3) / 1e12,
                           "final_loss": float(loss)}}
+        if world > 1:
+            s = dp._sync
+            out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "buckets": len(s.buckets) if s is not None else 0,
+                           "bucket_elems": [e - b for _, b, e in s.buckets] if s is not None else [],
+                           "allreduce_exposed_ms": exposed,
+                           "note": "allreduce_exposed_ms = mean time per step the compute stream waits in finish() after its last "
+                                   "backward kernel for the side stream's all-reduce buckets (HIP events, rank 0)"}
         if roof is not None:
-            # whole step against the MFMA roofline (SURVEY 8d's primary bound) and its HBM bytes against the compulsory bytes
+            # SURVEY 8d's primary bound is the MFMA roofline of the WHOLE step: that goes first; the dominant kernel family's
+            # HBM-roofline view (HIP events around its launches) rides along as `hbm_family`
             comp = args.batch * COMPULSORY_FWD_BYTES_PER_IMAGE * COMPULSORY_TRAIN_FACTOR + OPTIMIZER_BYTES_PER_STEP
-            st, st_src = stored_traffic("r02_pmc_step_traffic.json")
+            st, st_src = stored_traffic(STEP_TRAFFIC_FILE)
             hbm_step = st["hbm_bytes_per_step"] if st and st_src["matches_this_library"] and args.batch == 32 else None
-            roof["step"] = {"mfma_frac": out["config"]["step_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS,
-                            "algorithmic_tflop_per_step": args.batch * FLOP_PER_IMAGE_TRAIN / 1e12,
-                            "hbm_bytes_per_step": hbm_step, "hbm_bytes_source": st_src,
-                            "compulsory_bytes_per_step": comp,
-                            "traffic_ratio": (hbm_step / comp) if hbm_step else None}
-            out["roofline"] = roof
+            tfl_step = out["config"]["step_tflops_per_gpu"]
+            out["roofline"] = {"bound": "mfma", "kernel": "whole cfg3 train step (every kernel of fwd + loss + bwd + clip + AdamW; algorithmic, "
+                                                          "un-padded FLOPs of SURVEY 8d / BASELINE.md section 2)",
+                               "achieved": tfl_step, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl_step / MFMA_BF16_PEAK_TFLOPS,
+                               "traffic": hbm_step, "traffic_source": st_src,
+                               "step": {"mfma_frac": tfl_step / MFMA_BF16_PEAK_TFLOPS,
+                                        "algorithmic_tflop_per_step": args.batch * FLOP_PER_IMAGE_TRAIN / 1e12,
+                                        "hbm_bytes_per_step": hbm_step, "hbm_bytes_source": st_src,
+                                        "hbm_gbs": (hbm_step / (ms_per_step * 1e-3) / 1e9) if hbm_step else None,
+                                        "compulsory_bytes_per_step": comp,
+                                        "traffic_ratio": (hbm_step / comp) if hbm_step else None},
+                               "hbm_family": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["psnr_delta_db"] = None
+            try:
+                q = psnr_delta(model)
+                out["psnr_delta_db"] = q["psnr_delta_db"]
+                out["cpu_baseline"]["quality"] = q
+            except Exception as e:      # the quality leg must not take the timing line down
+                out["cpu_baseline"]["quality"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

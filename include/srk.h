@@ -73,6 +73,16 @@ int srk_window_attention_bwd(const uint16_t* qkv, const float* bias_dense, const
                              float* d_table, void* slab, int64_t B_, int nH, float scale, const srk_win_geom* geom,
                              srk_stream_t stream);
 size_t srk_window_attention_bwd_scratch(int64_t B_, int nH);
+/* The same gradient with q/k/v RE-PROJECTED from the saved LayerNorm output and the gradient of the output projection folded in
+ * (csrc/attn_bwd_fused.hip; classical width only: nH = 6, head_dim padded to 32, C padded to 192, B_ >= number of CUs; anything
+ * else returns SRK_E_UNSUPPORTED).  network_swinir.py:121-143 backwards: xn bf16 [B_*64][lda] = norm1 output in window order,
+ * w_qkv bf16 [576][192] / b_qkv fp32 [576] (packed, q rows first, heads padded 30 -> 32), d_x1 bf16 [B_*64][ldg] = gradient of
+ * the attention branch output in window order, w_proj_t bf16 [192 attention channel][192 channel] (d attn_out = d_x1 . w_proj_t^T),
+ * d_qkv bf16 [B_*64][576]; d_table fp32 [225][6] is ACCUMULATED; slab = scratch of ..._bwd_fused_scratch() bytes. */
+int srk_window_attention_bwd_fused(const uint16_t* xn, int lda, const uint16_t* w_qkv, const float* b_qkv, float scale,
+                                   const uint16_t* d_x1, int ldg, const uint16_t* w_proj_t, const float* bias_dense, uint16_t* d_qkv,
+                                   float* d_table, void* slab, int64_t B_, int nH, const srk_win_geom* geom, srk_stream_t stream);
+size_t srk_window_attention_bwd_fused_scratch(int64_t B_, int nH);
 /* dense bias [nH][64][64] from table [225][nH]   network_swinir.py:127-129 */
 int srk_rel_pos_bias_expand(const float* table, float* bias_dense, int nH, srk_stream_t stream);
 /* y[M][N] = a[M][K] . w[N][K]^T + bias  (bf16 in, fp32 accumulate, bf16 out); K % 64 == 0, N % 64 == 0 */
@@ -110,6 +120,9 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   "block_light" 1 (default) / 0: SwinIR-light width (C <= 64, 6 heads x d <= 16, hidden <= 128), inference: each Swin block is
  *   ONE kernel (csrc/block_light.hip: LayerNorms, qkv, window attention, proj, MLP and both residuals of a window in LDS and
  *   registers) or the layer-per-launch path.
+ *   "attn_bwd_fused" 1 (default) / 0: attention backward with q/k/v re-projected from the saved norm1 output and the output-
+ *   projection dgrad folded in (csrc/attn_bwd_fused.hip; classical width; the training forward then stores no q/k/v), or the
+ *   dgrad GEMM + csrc/attn.hip on q/k/v saved by the forward.  Read when a training forward lays out its workspace.
  *   "attn_fused" 2 (default) / 1 / 0: qkv projection + window attention forward in one kernel per window
  *   (csrc/attn_fused.hip; classical width: 6 heads x 32, C padded to 192) as three 4-wave workgroups per CU (2) or one 8-wave
  *   workgroup per CU (1), or the projection GEMM + attention kernel (0).

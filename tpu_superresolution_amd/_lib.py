@@ -73,6 +73,8 @@ _SIGNATURES = {
     "srk_window_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _geom_p, _vp]),
     "srk_window_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _geom_p, _vp]),
     "srk_window_attention_bwd_scratch": (_sz, [_i64, _i]),
+    "srk_window_attention_bwd_fused": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _geom_p, _vp]),
+    "srk_window_attention_bwd_fused_scratch": (_sz, [_i64, _i]),
     "srk_rel_pos_bias_expand": (_i, [_vp, _vp, _i, _vp]),
     "srk_linear_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srk_linear_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

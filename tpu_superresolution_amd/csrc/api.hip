@@ -161,6 +161,30 @@ int srk_window_attention_bwd(const uint16_t* qkv, const float* bias_dense, const
   return srk_launch_attn_bwd(qkv, bias_dense, d_out, d_qkv, (float*)slab, d_table, B_, nH, g, scale, (hipStream_t)stream);
 }
 
+size_t srk_window_attention_bwd_fused_scratch(int64_t B_, int nH) {
+  return (size_t)srk_qkv_attn_bwd_slabs(B_, nH, nH * 32, 192) * nH * 4096 * sizeof(float);
+}
+
+int srk_window_attention_bwd_fused(const uint16_t* xn, int lda, const uint16_t* w_qkv, const float* b_qkv, float scale,
+                                   const uint16_t* d_x1, int ldg, const uint16_t* w_proj_t, const float* bias_dense, uint16_t* d_qkv,
+                                   float* d_table, void* slab, int64_t B_, int nH, const srk_win_geom* geom, srk_stream_t stream) {
+  REQ_PTR(xn); REQ_PTR(w_qkv); REQ_PTR(d_x1); REQ_PTR(w_proj_t); REQ_PTR(bias_dense); REQ_PTR(d_qkv); REQ_PTR(d_table); REQ_PTR(slab);
+  REQ_PTR(geom); REQ_ALIGN(xn); REQ_ALIGN(w_qkv); REQ_ALIGN(d_x1); REQ_ALIGN(w_proj_t); REQ_ALIGN(d_qkv); REQ_ALIGN(slab);
+  WinGeom g;
+  int rc = make_geom(geom, &g, "window_attention_bwd_fused");
+  if (rc) return rc;
+  SRK_REQUIRE(B_ > 0 && B_ % g.nW == 0, SRK_E_SHAPE, "window_attention_bwd_fused: B_=%lld nW=%d", (long long)B_, g.nW);
+  const int nslab = srk_qkv_attn_bwd_slabs(B_, nH, nH * 32, 192);
+  SRK_REQUIRE(nslab > 0, SRK_E_UNSUPPORTED,
+              "window_attention_bwd_fused: covers 6 heads x 32, K = 192 and at least one window per CU (got nH=%d B_=%lld)", nH,
+              (long long)B_);
+  rc = srk_launch_qkv_attn_bwd(xn, lda, w_qkv, b_qkv, scale, d_x1, ldg, w_proj_t, bias_dense, d_qkv, (float*)slab, B_, nH, nH * 32, 192, g,
+                               (hipStream_t)stream);
+  SRK_REQUIRE(rc != SRK_NOT_COVERED, SRK_E_UNSUPPORTED, "window_attention_bwd_fused: the kernel cannot run on this build / shape");
+  if (rc) return rc;
+  return srk_launch_rpb_reduce((const float*)slab, d_table, nslab, nH, (hipStream_t)stream);
+}
+
 int srk_rel_pos_bias_expand(const float* table, float* bias_dense, int nH, srk_stream_t stream) {
   REQ_PTR(table); REQ_PTR(bias_dense);
   return srk_launch_rpb_expand(table, bias_dense, nH, (hipStream_t)stream);
@@ -247,6 +271,10 @@ int srk_set_option(const char* name, int value) {
   REQ_PTR(name);
   if (strcmp(name, "gemm_stream") == 0) {
     srk_gemm_stream_enable(value);
+    return SRK_OK;
+  }
+  if (strcmp(name, "attn_bwd_fused") == 0) {
+    srk_attn_bwd_fused_enable(value);
     return SRK_OK;
   }
   if (strcmp(name, "attn_fused") == 0) {

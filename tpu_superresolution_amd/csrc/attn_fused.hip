@@ -485,6 +485,7 @@ int g_fused_cus = 0;
 }  // namespace
 
 void srk_attn_fused_enable(int on) { g_attn_fused = on < 0 ? 0 : (on > 2 ? 2 : on); }
+int srk_attn_fused_mode() { return g_attn_fused; }
 
 // SRK_NOT_COVERED (1) when the fused kernel does not apply: the caller then runs the projection GEMM and srk_launch_attn_fwd.
 int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const float* bias, float scale, bf16_t* qkv,

@@ -9,6 +9,7 @@
 int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const float* bias, float scale, bf16_t* qkv, const float* biasd,
                             bf16_t* ao, long long B_, int nH, int CA, int K, WinGeom geom, hipStream_t stream);
 void srk_attn_fused_enable(int on);
+int srk_attn_fused_mode();
 // block_light.hip: one whole Swin block of the light width per launch (inference); SRK_NOT_COVERED when the shape is another
 void srk_block_light_enable(int on);
 int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const float* n1w, const float* n1b, const float* n2w, const float* n2b,
@@ -20,6 +21,14 @@ int srk_attn_bwd_slabs(long long B_, int nH, int* wpw_out);
 int srk_launch_attn_bwd(const bf16_t* qkv, const float* biasd, const bf16_t* dao, bf16_t* dqkv, float* dbias_slab,
                         float* dtable, long long B_, int nH, WinGeom geom, float scale, hipStream_t stream);
 int srk_launch_rpb_expand(const float* table, float* biasd, int nH, hipStream_t stream);
+// attn_bwd_fused.hip: attention backward of one window per workgroup pass with q/k/v re-projected from xn1 and the output-projection
+// dgrad folded in (classical width); SRK_NOT_COVERED -> dproj GEMM + srk_launch_attn_bwd on saved q/k/v
+void srk_attn_bwd_fused_enable(int on);
+int srk_attn_bwd_fused_enabled();
+int srk_qkv_attn_bwd_slabs(long long B_, int nH, int CA, int K);    // d(bias) slabs it writes; 0 = not covered
+int srk_launch_qkv_attn_bwd(const bf16_t* xn, int lda, const bf16_t* Wqkv, const float* bqkv, float scale, const bf16_t* g, int ldg,
+                            const bf16_t* WprojT, const float* biasd, bf16_t* dqkv, float* slab, long long B_, int nH, int CA, int K,
+                            WinGeom geom, hipStream_t stream);
 
 int srk_launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* yb, float* yf, float* mean,
                       float* rstd, int rows, int C, int CP, const WinGeom* geom, hipStream_t stream);

@@ -55,6 +55,8 @@ struct BlockAct {
 
 struct Workspace {
   int B = 0, H0 = 0, W0 = 0, H = 0, W = 0, training = 0;
+  int attn_recompute = 0;      // training: the attention backward re-projects q/k/v (attn_bwd_fused.hip); the forward stores none
+  int opt_sig = 0;             // option values the layout depends on
   long long T = 0;
   size_t img4, f0, x0, mean_pe, rstd_pe;
   std::vector<BlockAct> blk;
@@ -227,12 +229,19 @@ struct Arena {
   }
 };
 
+// option values that change the workspace layout: a forward re-lays the workspace out when they differ from the laid-out ones
+int layout_option_sig() { return srk_attn_bwd_fused_enabled() | (srk_attn_fused_mode() << 1); }
+
 void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int W0, int training) {
   w = Workspace();
   w.B = B; w.H0 = H0; w.W0 = W0; w.training = training;
   w.H = (H0 + 7) / 8 * 8;
   w.W = (W0 + 7) / 8 * 8;
   w.T = (long long)B * w.H * w.W;
+  w.opt_sig = layout_option_sig();
+  w.attn_recompute = training != 0 && srk_attn_fused_mode() != 0;   // the forward that stores no q/k/v is the fused one
+  for (const BlockW& b : p->blocks)
+    if (srk_qkv_attn_bwd_slabs(w.T / 64, b.nH, b.CA, p->CP) == 0) w.attn_recompute = 0;
   const size_t T = (size_t)w.T;
   const size_t CP = p->CP, HP = p->HP;
   Arena a;
@@ -281,7 +290,7 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
         ba.xn1w = a.get(pre + "xn1w", T * CP * 2);
         ba.mean1 = a.get(pre + "mean1", T * 4);
         ba.rstd1 = a.get(pre + "rstd1", T * 4);
-        ba.qkv = a.get(pre + "qkv", T * 3 * bw.CA * 2);
+        ba.qkv = w.attn_recompute ? 0 : a.get(pre + "qkv", T * 3 * bw.CA * 2);
         ba.ao = a.get(pre + "ao", T * bw.CA * 2);
         ba.x1 = a.get(pre + "x1", T * CP * 4);
         ba.xn2 = a.get(pre + "xn2", T * CP * 2);
@@ -350,7 +359,9 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
     w.dqkv = a.get("dqkv", T * 3 * maxCA * 2);
     int maxH = 1;
     for (const BlockW& b : p->blocks) maxH = b.nH > maxH ? b.nH : maxH;
-    w.slab = a.get("slab", (size_t)srk_attn_bwd_slabs(w.T / 64, 1, nullptr) * maxH * 4096 * 4);
+    size_t nslab = (size_t)srk_attn_bwd_slabs(w.T / 64, 1, nullptr);
+    if (w.attn_recompute) nslab = (size_t)srk_qkv_attn_bwd_slabs(w.T / 64, p->blocks[0].nH, p->blocks[0].CA, p->CP);
+    w.slab = a.get("slab", nslab * maxH * 4096 * 4);
     w.wgpart = a.get("wgpart", WS_WORKSPACE_BYTES);      // split partials of the streaming weight-gradient kernels
     w.gfb = a.get("gfb", T * CP * 2);
     w.gfb32 = a.get("gfb32", T * CP * 4);
@@ -731,11 +742,13 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
       ln1_done = false;
       // qkv projection (q scaled, :121-124) + softmax(qk^T + bias + mask) v (:125-142): one kernel per window where it applies
       const int rc_fused = srk_launch_qkv_attn_fwd(c.at<bf16_t>(ba.xn1w), CP, c.packed + bw.Wqkv, c.side + bw.bqkv, bw.scale,
-                                                   w.training ? c.at<bf16_t>(ba.qkv) : nullptr, c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, bw.CA, CP,
+                                                   (w.training && !w.attn_recompute) ? c.at<bf16_t>(ba.qkv) : nullptr, c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, bw.CA, CP,
                                                    geom, st);
       if (rc_fused != SRK_NOT_COVERED) {
         RUN(rc_fused);
       } else {
+        SRK_REQUIRE(!w.attn_recompute, SRK_E_STATE, "forward: the fused qkv + attention kernel is off (option attn_fused) while the "
+                    "workspace was laid out for the re-projecting attention backward; set attn_bwd_fused 0 as well");
         {
           GemmParams g = {};
           g.A = c.at<bf16_t>(ba.xn1w); g.lda = CP; g.Wt = c.packed + bw.Wqkv; g.M = T; g.N = 3 * bw.CA; g.K = CP;
@@ -830,7 +843,8 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
   SRK_REQUIRE(B > 0 && H0 > 0 && W0 > 0, SRK_E_SHAPE, "forward: bad shape B=%d H=%d W=%d", B, H0, W0);
   srk_swinir_plan* p = plan;
   Workspace& w = p->ws;
-  if (w.B != B || w.H0 != H0 || w.W0 != W0 || w.training != training) layout_workspace(p, w, B, H0, W0, training);
+  if (w.B != B || w.H0 != H0 || w.W0 != W0 || w.training != training || w.opt_sig != layout_option_sig())
+    layout_workspace(p, w, B, H0, W0, training);
   SRK_REQUIRE((H0 % 8 == 0 || H0 >= 2) && (W0 % 8 == 0 || W0 >= 2), SRK_E_SHAPE, "forward: reflect padding needs size >= 2");
   SRK_REQUIRE(w.H - H0 < H0 && w.W - W0 < W0, SRK_E_SHAPE,
               "forward: reflect padding %dx%d -> %dx%d needs pad < size (as torch 'reflect')", H0, W0, w.H, w.W);
@@ -1177,17 +1191,30 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
                                 params + bw.n2w, c.at<float>(w.gx2), c.at<bf16_t>(w.gxbw), grads + bw.n2w, grads + bw.n2b, T, C, CP,
                                 &geom, 0, 0, 1, 1, ds_attn, HW, st));
         }
-        {  // d attn_out = d x1(window order) . Wproj
-          GemmParams g = {};
-          g.A = c.at<bf16_t>(w.gxbw); g.lda = CP; g.Wt = c.packed + bw.WprojT; g.M = T; g.N = bw.CA; g.K = CP;
-          g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA; g.flops = fl_proj; g.bytes = (double)T * 4.0 * C + 2.0 * C * C;
-          RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
-        }
         wq[2] = lin_wgrad(c, c.at<bf16_t>(w.gxbw), CP, c.at<bf16_t>(ba.ao), bw.CA, T, bw.Wproj, bw.bproj, fl_proj);
         // the slabs of d(bias) are reduced into the table gradient by the reduce launch of the weight gradients below
-        RUN(srk_launch_attn_bwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(w.dao), c.at<bf16_t>(w.dqkv),
-                                c.at<float>(w.slab), nullptr, T / 64, bw.nH, geom, bw.scale, st));
-        const RpbJob rpb = {c.at<float>(w.slab), grads + bw.rpb, srk_attn_bwd_slabs(T / 64, bw.nH, nullptr), bw.nH};
+        int nslab;
+        if (w.attn_recompute) {
+          // d qkv straight from xn1 (q/k/v re-projected) and d x1 (d attn_out = d x1 . Wproj inside the kernel)
+          const int rc_abf = srk_launch_qkv_attn_bwd(c.at<bf16_t>(ba.xn1w), CP, c.packed + bw.Wqkv, c.side + bw.bqkv, bw.scale,
+                                                     c.at<bf16_t>(w.gxbw), CP, c.packed + bw.WprojT, c.side + bw.biasd,
+                                                     c.at<bf16_t>(w.dqkv), c.at<float>(w.slab), T / 64, bw.nH, bw.CA, CP, geom, st);
+          SRK_REQUIRE(rc_abf != SRK_NOT_COVERED, SRK_E_STATE, "backward: the re-projecting attention backward cannot run but the "
+                      "forward stored no q/k/v (option attn_bwd_fused changed between forward and backward?)");
+          RUN(rc_abf);
+          nslab = srk_qkv_attn_bwd_slabs(T / 64, bw.nH, bw.CA, CP);
+        } else {
+          {  // d attn_out = d x1(window order) . Wproj
+            GemmParams g = {};
+            g.A = c.at<bf16_t>(w.gxbw); g.lda = CP; g.Wt = c.packed + bw.WprojT; g.M = T; g.N = bw.CA; g.K = CP;
+            g.outb = c.at<bf16_t>(w.dao); g.ldo = bw.CA; g.flops = fl_proj; g.bytes = (double)T * 4.0 * C + 2.0 * C * C;
+            RUN(srk_launch_gemm(LD_ROWS, EP_BF16, g, st));
+          }
+          RUN(srk_launch_attn_bwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(w.dao), c.at<bf16_t>(w.dqkv),
+                                  c.at<float>(w.slab), nullptr, T / 64, bw.nH, geom, bw.scale, st));
+          nslab = srk_attn_bwd_slabs(T / 64, bw.nH, nullptr);
+        }
+        const RpbJob rpb = {c.at<float>(w.slab), grads + bw.rpb, nslab, bw.nH};
         wq[3] = lin_wgrad(c, c.at<bf16_t>(w.dqkv), 3 * bw.CA, c.at<bf16_t>(ba.xn1w), CP, T, bw.Wqkv, bw.bqkv, fl_qkv);
         RUN(srk_launch_wgrad_multi_rpb(wq, 4, &rpb, st));   // reads gxb2 (as d x2): must precede the kernel that overwrites it
         {  // d xn1 (window order) = d qkv . Wqkv

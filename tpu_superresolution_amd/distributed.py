@@ -84,6 +84,8 @@ class GradSynchronizer:
         self._side: Optional[torch.cuda.Stream] = None
         self._works = []
         self._flat: Optional[torch.Tensor] = None
+        self.time_exposed = False          # bench.py: bracket finish() with events on the compute stream
+        self._exposed = []                 # (event before the joins, event after) per finish()
 
     def bind(self, flat_grad: torch.Tensor) -> None:
         self._flat = flat_grad
@@ -107,11 +109,28 @@ class GradSynchronizer:
 
     def finish(self) -> None:
         """Make the current stream wait for every outstanding bucket."""
+        timed = self.time_exposed and self._side is not None and self.world > 1
+        if timed:     # the compute stream reaches ev0 when its last backward kernel is done and ev1 when the last bucket is
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream())
         for w in self._works:
             w.wait()
         self._works.clear()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        if timed:
+            ev1.record(torch.cuda.current_stream())
+            self._exposed.append((ev0, ev1))
+
+    def exposed_ms(self) -> Optional[float]:
+        """Mean time per step the compute stream spent waiting for all-reduce buckets after its last backward kernel
+        (call after a device synchronize); None when nothing was timed."""
+        if not self._exposed:
+            return None
+        total = sum(a.elapsed_time(b) for a, b in self._exposed)
+        n = len(self._exposed)
+        self._exposed.clear()
+        return total / n
 
 
 class DataParallelSwinIR:

@@ -128,6 +128,22 @@ def window_attention_bwd(qkv: torch.Tensor, bias_dense: torch.Tensor, d_out: tor
     return d_qkv, d_table
 
 
+def window_attention_bwd_fused(xn: torch.Tensor, w_qkv: torch.Tensor, b_qkv: Optional[torch.Tensor], scale: float, d_x1: torch.Tensor,
+                               w_proj_t: torch.Tensor, bias_dense: torch.Tensor, H: int, W: int, shift: int):
+    """Attention backward with q/k/v re-projected from xn and the output-projection dgrad folded in (classical width).
+    xn, d_x1 bf16 [B_*64, 192] window order; w_qkv bf16 [576, 192]; w_proj_t bf16 [192, 192]
+    -> (d_qkv bf16 [B_*64, 576], d_table fp32 [225, 6])."""
+    B_ = xn.shape[0] // 64
+    nH = bias_dense.shape[0]
+    d_qkv = torch.empty((B_ * 64, 3 * nH * 32), dtype=torch.bfloat16, device=xn.device)
+    d_table = torch.zeros((225, nH), dtype=torch.float32, device=xn.device)
+    slab = torch.empty(max(16, lib().srk_window_attention_bwd_fused_scratch(B_, nH)), dtype=torch.uint8, device=xn.device)
+    check(lib().srk_window_attention_bwd_fused(_p(xn), xn.stride(0), _p(w_qkv), _p(b_qkv), float(scale), _p(d_x1), d_x1.stride(0),
+                                               _p(w_proj_t), _p(bias_dense), _p(d_qkv), _p(d_table), _p(slab), B_, nH,
+                                               _geom(H, W, shift), _stream()))
+    return d_qkv, d_table
+
+
 def rel_pos_bias_expand(table: torch.Tensor) -> torch.Tensor:
     nH = table.shape[1]
     out = torch.empty((nH, 64, 64), dtype=torch.float32, device=table.device)
