@@ -200,7 +200,8 @@ int srk_adamw_clip_step(float* params, const float* grads, float* exp_avg, float
 /* ---- generic GEMM / 3x3 conv with the fused epilogues, for host-orchestrated models (HAT: tpu_superresolution_amd/hat_arch.py)
  * D[m][n] = sum_k A[m][k] W[n][k] (+ epilogue).  A bf16: SRK_LD_ROWS [M][lda]; SRK_LD_CONV3 NHWC [B][H][Wd][CinP] (3x3, pad 1,
  * K = 9 * CinP tap-major).  W bf16 [N][K].  N % 64 == 0 (N == 16 for the image head), K % 64 == 0. */
-enum { SRK_LD_ROWS = 0, SRK_LD_CONV3 = 1 };
+enum { SRK_LD_ROWS = 0, SRK_LD_CONV3 = 1,
+       SRK_LD_CONV3_PS = 2 /* 3x3 conv whose NHWC source is stored pixel-shuffled by r (Cs stored channels): dgrad of conv + PixelShuffle */ };
 enum { SRK_EP_BF16 = 0,       /* outb = bf16(v + bias) */
        SRK_EP_GELU = 3,       /* outb2 = bf16(gelu(u)), u = v + bias; outb = bf16(u) if not null (kept for a backward pass) */
        SRK_EP_RES = 4,        /* outf = res + v + bias (fp32) [+ outb bf16 copy] [+ LayerNorm of the new row -> xn_out, N == 64/128/192] */
@@ -209,6 +210,9 @@ enum { SRK_EP_BF16 = 0,       /* outb = bf16(v + bias) */
        SRK_EP_IMG = 8,        /* N == 16: outf NCHW image [B][Cimg][Hc][Wc] = v * inv_range + mean[c] (crop) */
        SRK_EP_PS_IMG = 9,     /* N == 16: conv + PixelShuffle(r) straight into the NCHW image (UpsampleOneStep), n = c*r*r + i*r + j */
        SRK_EP_RES_BF16 = 10,  /* outb = bf16(res + v + bias) */
+       SRK_EP_DGELU = 5,      /* outb = bf16(v * gelu'(aux))            (backward through an exact-erf GELU; aux = pre-activation) */
+       SRK_EP_DLRELU = 11,    /* outb = bf16(v * (aux > 0 ? 1 : scale)) (backward through LeakyReLU; aux = its output) */
+       SRK_EP_F32_BF16 = 12,  /* outf = v (fp32) [+ outb = bf16(v)] */
        SRK_EP_MLP_FUSED = 100 /* (reserved; see srk_mlp_fused_fwd) */ };
 typedef struct {
   int loader, epilogue;
@@ -224,6 +228,7 @@ typedef struct {
   float scale;                 /* SRK_EP_LRELU slope */
   float inv_range; float mean[4]; int Cimg, Hc, Wc;     /* SRK_EP_IMG */
   void* xn_out; float* xn_mean; float* xn_rstd; const float* xn_gamma; const float* xn_beta; int xn_C;   /* SRK_EP_RES fused LayerNorm */
+  const float* rowscale; int rows_per_sample;   /* SRK_EP_RES: outf = res + rowscale[m / rows_per_sample] * (v + bias)  (DropPath factor per sample) or null */
 } srk_gemm_args;
 int srk_gemm_ex(const srk_gemm_args* args, srk_stream_t stream);
 /* Mlp.forward + residual (+ next LayerNorm) in one kernel (csrc/gemm_stream.hip): out = res + gelu(xn W1^T + b1) W2^T + b2.
@@ -268,6 +273,52 @@ int srk_channel_gate_act(const uint16_t* x, void* workspace, const float* w1, co
 /* HAB.forward :322-323: x += conv * gate[sample] in place (fp32 [rows][CP]) and, if xn != null, xn = bf16(LayerNorm(x)) */
 int srk_cab_add_ln(float* x, const uint16_t* conv, const float* gate, const float* gamma, const float* beta, uint16_t* xn, int64_t rows,
                    int rows_per_sample, int C, int CP, srk_stream_t stream);
+
+/* ---- training pieces for the host-orchestrated models (csrc/hat_train.hip, csrc/attn256_bwd.hip) ----------------------------------
+ * Gradient of srk_win256_attention_fwd (table-indexed bias, 16 x 16 windows; WindowAttention.forward hat_arch.py:163-197 and
+ * OCAB.forward :403-439 backwards).  d_out bf16 [T][ldo] raster = gradient of the attention output; d_qkv bf16 [T][ldq] in the
+ * layout of qkv (q gradient w.r.t. the UNSCALED q, as qkv holds it); d_table fp32 [table_rows][num_heads] is ACCUMULATED (the
+ * negative relative_position_index_OCA entries wrap, :911-918); scratch: srk_win256_attention_bwd_scratch bytes.  In the
+ * overlapping form the key / value gradients of a token are summed over the (up to four) key windows that hold it. */
+size_t srk_win256_attention_bwd_scratch(int B, int H, int W, int num_heads, int CA, int table_rows, int overlap);
+int srk_win256_attention_bwd(const uint16_t* qkv, int ldq, int CA, const float* table, int table_rows, const uint16_t* d_out, int ldo,
+                             uint16_t* d_qkv, float* d_table, void* scratch, int B, int H, int W, int shift_y, int shift_x, int num_heads,
+                             float scale, int overlap, srk_stream_t stream);
+/* Gradient of `x += conv * gate[sample]`, gate = srk_channel_gate(conv) (HAB.forward :322 with CAB :41-75): g fp32 [B*HW][CP] is the
+ * gradient of the sum, conv bf16 the second CAB conv's output, gate fp32 [B][CP] as the forward produced it.  d_conv bf16 [B*HW][CP] =
+ * g * gate + (gradient through the average pool); dw1 [S][C], db1 [S], dw2 [C][S], db2 [C] are ACCUMULATED; dmean fp32 [B][CP] scratch. */
+size_t srk_cab_bwd_workspace(int B, int HW, int CP);
+int srk_cab_bwd(const uint16_t* conv, const float* g, const float* gate, void* workspace, const float* w1, const float* b1, const float* w2,
+                const float* b2, float out_scale, float* dw1, float* db1, float* dw2, float* db2, float* dmean, uint16_t* d_conv, int B, int HW,
+                int C, int CP, int S, srk_stream_t stream);
+/* LayerNorm backward over C of CP columns: dy bf16 [rows][CP]; x, mean, rstd as srk_layernorm_fwd saw / produced them;
+ * gx fp32 [rows][CP] = (accumulate ? gx : 0) + dx; gx_bf16 (optional) = bf16(gx); dgamma / dbeta fp32 [C] ACCUMULATED. */
+int srk_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* gx,
+                      uint16_t* gx_bf16, float* dgamma, float* dbeta, int rows, int C, int CP, int accumulate, srk_stream_t stream);
+/* element-wise helpers of a backward pass: a += b and ab_bf16 = bf16(a); a += float(b); out = a + b   (n % 4 == 0) */
+int srk_add_f32_bf16(float* a, const float* b, uint16_t* ab_bf16, int64_t n, srk_stream_t stream);
+int srk_add_bf16_into_f32(float* a, const uint16_t* b, int64_t n, srk_stream_t stream);
+int srk_add_f32(float* out, const float* a, const float* b, int64_t n, srk_stream_t stream);
+/* image head backwards: d_pred fp32 NCHW [B][Cimg][Hc][Wc] -> gy fp32 [B*H*W][CoP] (times inv_range; r > 1: un-pixel-shuffled);
+ * weight / input gradients of a 3x3 conv with few output channels (conv_last), fp32 parameters [Co][Cin][3][3] */
+int srk_img_grad_prep(const float* d_pred, float* gy, int B, int Cimg, int Hc, int Wc, int H, int W, int r, int CoP, float inv_range,
+                      srk_stream_t stream);
+int srk_smallconv_wgrad(const uint16_t* x, const float* gy, float* dw, float* db, int B, int H, int W, int Cin, int CinP, int Co, int CoP,
+                        srk_stream_t stream);
+int srk_smallconv_dgrad(const float* gy, const float* weight, uint16_t* dx, int B, int H, int W, int Cin, int CinP, int Co, int CoP,
+                        srk_stream_t stream);
+/* conv_first backwards: dw [C][Cin][3][3], db [C] ACCUMULATED from the padded NHWC4 image and gy fp32 [B*H*W][CP] */
+int srk_stem_wgrad(const float* img4, const float* gy, float* dw, float* db, int B, int H, int W, int Cin, int C, int CP, srk_stream_t stream);
+/* srk_conv3x3_wgrad_bf16 with y stored pixel-shuffled by r (the gradient of a conv + PixelShuffle(r) output, Cs stored channels) */
+int srk_conv3x3_wgrad_ps_bf16(const uint16_t* y, const uint16_t* x, float* dw, float* db, int B, int H, int W, int CinP, int N, int r, int Cs,
+                              srk_stream_t stream);
+/* srk_mlp_fused_fwd that also stores u = xn W1^T + b1 and h = gelu(u) (bf16 [M][384]) for a backward pass */
+int srk_mlp_fused_fwd_train(const uint16_t* xn, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* res,
+                            float* out, uint16_t* out_bf16, uint16_t* u_out, uint16_t* h_out, uint16_t* xn_next, float* xn_mean,
+                            float* xn_rstd, const float* xn_gamma, const float* xn_beta, int xn_C, const float* rowscale, int rows_per_sample,
+                            int M, srk_stream_t stream);
+/* dst[m][c] = bf16(float(src[m][c]) * f[m / rows_per_sample])  (a DropPath factor on a bf16 gradient copy; dst may alias src) */
+int srk_rowscale_bf16(const uint16_t* src, uint16_t* dst, const float* f, int64_t rows, int rows_per_sample, int CP, srk_stream_t stream);
 
 /* ---- DAT (reference dat_arch.py), inference pieces; token-major bf16 [T][ld], channels padded per head to 32 -------------------------
  * Depth-wise 3x3 conv, pad 1, over C8*8 channels of x (column 0 of the slice given): out = act((conv(x)) * scale + shift) * mul.

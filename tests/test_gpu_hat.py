@@ -166,5 +166,132 @@ def test_hat_errors_are_loud():
         m(torch.rand(1, 3, 32, 32))
     with pytest.raises(NotImplementedError, match="window_size=8"):
         T.HAT(**{**cfg.kwargs(), "window_size": 8}).cuda().eval()(torch.rand(1, 3, 32, 32, device="cuda"))
-    with pytest.raises(NotImplementedError, match="training is not built"):
-        m.cuda().train()(torch.rand(1, 3, 32, 32, device="cuda"))
+
+
+# ---- training (csrc/attn256_bwd.hip, csrc/hat_train.hip, tpu_superresolution_amd/hat_train.py) -------------------------------------------
+@pytest.mark.parametrize("shift,overlap,H,W", [(0, 0, 32, 48), (8, 0, 32, 48), (8, 0, 64, 32), (0, 8, 32, 48), (0, 8, 16, 16)])
+def test_win256_attention_backward_vs_autograd(shift, overlap, H, W):
+    """d q / d k / d v / d table of the table-indexed 256-query window attention against autograd on the fp32 restatement (same
+    bf16-rounded inputs).  The overlapping form sums the key / value gradients of a token over the key windows that hold it and
+    drops the zero-padded keys; negative relative_position_index_OCA entries land on the wrapped table rows."""
+    check, L = _lib()
+    B, nH, ws = 2, 3, 16
+    CA = nH * 32
+    g = torch.Generator().manual_seed(H * 5 + W + shift + overlap)
+    qkv = (torch.randn(B * H * W, 3 * CA, generator=g) * 0.8).to(torch.bfloat16)
+    qkv.view(B * H * W, 3, nH, 32)[..., 30:] = 0
+    dout = (torch.randn(B * H * W, CA, generator=g) * 0.5).to(torch.bfloat16)
+    dout.view(B * H * W, nH, 32)[..., 30:] = 0
+    rows = (2 * ws + overlap - 1) ** 2
+    table = torch.randn(rows, nH, generator=g) * 0.5
+    scale = 30 ** -0.5
+    qr = qkv.float().clone().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    dense = HO.oca_bias(tr, ws, ws + overlap) if overlap else HO.sa_bias(tr, ws)
+    _attn_reference(qr, dense, B, H, W, ws, shift, nH, scale, overlap).backward(dout.float())
+    st = torch.cuda.current_stream().cuda_stream
+    q_d, o_d, t_d = qkv.cuda(), dout.cuda(), table.cuda()
+    dqkv = torch.zeros(B * H * W, 3 * CA, dtype=torch.bfloat16, device="cuda")
+    dtab = torch.zeros(rows, nH, device="cuda")
+    scratch = torch.empty(int(L.srk_win256_attention_bwd_scratch(B, H, W, nH, CA, rows, overlap)), dtype=torch.uint8, device="cuda")
+    check(L.srk_win256_attention_bwd(q_d.data_ptr(), 3 * CA, CA, t_d.data_ptr(), rows, o_d.data_ptr(), CA, dqkv.data_ptr(), dtab.data_ptr(),
+                                     scratch.data_ptr(), B, H, W, shift, shift, nH, scale, overlap, st))
+    got, ref = dqkv.cpu().float().view(-1, 3, nH, 32), qr.grad.view(-1, 3, nH, 32)
+    for i, name in enumerate("qkv"):
+        err = float((got[:, i] - ref[:, i]).abs().max())
+        assert err <= 2.5e-2 * float(ref[:, i].abs().max()), f"d{name}: max err {err:.3e} vs max|ref| {float(ref[:, i].abs().max()):.3e}"
+    assert float(got[..., 30:].abs().max()) == 0.0
+    err_t = float((dtab.cpu() - tr.grad).abs().max())
+    assert err_t <= 2e-2 * max(1.0, float(tr.grad.abs().max())), f"d table: max err {err_t:.3e} vs {float(tr.grad.abs().max()):.3e}"
+
+
+def test_cab_backward_vs_autograd():
+    check, L = _lib()
+    B, HW, C, CP, S = 3, 700, 180, 192, 6
+    g = torch.Generator().manual_seed(2)
+    conv = torch.zeros(B * HW, CP)
+    conv[:, :C] = torch.randn(B * HW, C, generator=g)
+    conv = conv.to(torch.bfloat16)
+    grad = torch.zeros(B * HW, CP)
+    grad[:, :C] = torch.randn(B * HW, C, generator=g)
+    w1, b1, w2, b2 = torch.randn(S, C, generator=g) * 0.3, torch.randn(S, generator=g), torch.randn(C, S, generator=g), torch.randn(C, generator=g)
+    cr = conv.float()[:, :C].clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    gate_ref = 0.01 * torch.sigmoid(torch.relu(cr.reshape(B, HW, C).mean(1) @ pr[0].t() + pr[1]) @ pr[2].t() + pr[3])
+    (cr * gate_ref.repeat_interleave(HW, 0)).backward(grad[:, :C])
+    st = torch.cuda.current_stream().cuda_stream
+    dev = [t.cuda() for t in (conv, w1, b1, w2, b2, grad)]
+    ws_ = torch.empty(int(L.srk_channel_gate_workspace(B, HW, CP)), dtype=torch.uint8, device="cuda")
+    gate = torch.empty(B, CP, device="cuda")
+    check(L.srk_channel_gate(dev[0].data_ptr(), ws_.data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), 0.01,
+                             gate.data_ptr(), B, HW, C, CP, S, st))
+    wsb = torch.empty(int(L.srk_cab_bwd_workspace(B, HW, CP)), dtype=torch.uint8, device="cuda")
+    dw1, db1, dw2, db2 = (torch.zeros_like(t, device="cuda") for t in (w1, b1, w2, b2))
+    dmean, dconv = torch.empty(B, CP, device="cuda"), torch.empty(B * HW, CP, dtype=torch.bfloat16, device="cuda")
+    check(L.srk_cab_bwd(dev[0].data_ptr(), dev[5].data_ptr(), gate.data_ptr(), wsb.data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(),
+                        dev[3].data_ptr(), dev[4].data_ptr(), 0.01, dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                        dmean.data_ptr(), dconv.data_ptr(), B, HW, C, CP, S, st))
+    for got, ref, name in ((dw1, pr[0].grad, "dw1"), (db1, pr[1].grad, "db1"), (dw2, pr[2].grad, "dw2"), (db2, pr[3].grad, "db2")):
+        assert float((got.cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())) + 1e-6, name
+    err = float((dconv.cpu().float()[:, :C] - cr.grad).abs().max())
+    assert err <= 1e-2 * float(cr.grad.abs().max()) and float(dconv.cpu().float()[:, C:].abs().max()) == 0.0
+
+
+def test_hat_tiny_gradients_vs_reference_golden():
+    """G13's training record (reference HAT, drop_path 0, L1 loss on a 2 x 3 x 32 x 32 batch): loss, the stored gradient tensors
+    (OCAB of layer 1, CAB of a shifted HAB, conv_first, conv_last) and the gradient norm of every parameter."""
+    import tpu_superresolution_amd as T
+    g, cfg, sd = hat_tiny_weights()
+    m = T.HAT(drop_path_rate=0.0, **cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(int(g["train.x_seed"])))
+    t = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(int(g["train.target_seed"])))
+    loss = torch.nn.functional.l1_loss(m(x.cuda()), t.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["train.loss"])) <= 2e-3 * float(g["train.loss"])
+    rels = []
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        n, ref = k[5:], torch.from_numpy(g[k])
+        p = params[n]
+        assert p.grad is not None and p.grad.shape == ref.shape, n
+        rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
+        assert rel <= 0.1, f"{n}: relative L2 error {rel:.3e}"
+        rels.append(rel)
+    assert float(np.median(rels)) <= 0.04
+    names, norms = [str(s) for s in g["train.grad_names"]], g["train.grad_norms"]
+    assert names == [n for n, _ in m.named_parameters()]
+    for n, ref in zip(names, norms):
+        got = float(params[n].grad.norm())
+        assert abs(got - float(ref)) <= 0.1 * float(ref) + 1e-7, f"{n}: |grad| {got:.4e} vs reference {float(ref):.4e}"
+    # accumulation semantics: a second backward doubles the gradients
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    torch.nn.functional.l1_loss(m(x.cuda()), t.cuda()).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=2e-3, atol=2e-6 * float(g1[n].abs().max()) + 1e-9), n
+
+
+def test_hat_train_step_with_drop_path_runs_and_learns():
+    """Train mode with the reference's default drop_path_rate (0.1): DropPath factors drawn per block and sample, a few AdamW steps
+    lower the loss."""
+    import tpu_superresolution_amd as T
+    g, cfg, sd = hat_tiny_weights()
+    m = T.HAT(drop_path_rate=0.1, **cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.0)
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 32, 32, device="cuda")
+    t = torch.rand(2, 3, 128, 128, device="cuda")
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(m(x), t)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

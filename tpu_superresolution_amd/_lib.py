@@ -43,11 +43,12 @@ class GemmArgs(C.Structure):
                 ("outb2", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("ldo", C.c_int), ("scale", C.c_float),
                 ("inv_range", C.c_float), ("mean", C.c_float * 4), ("Cimg", C.c_int), ("Hc", C.c_int), ("Wc", C.c_int),
                 ("xn_out", C.c_void_p), ("xn_mean", C.c_void_p), ("xn_rstd", C.c_void_p), ("xn_gamma", C.c_void_p),
-                ("xn_beta", C.c_void_p), ("xn_C", C.c_int)]
+                ("xn_beta", C.c_void_p), ("xn_C", C.c_int), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int)]
 
 
-LD_ROWS, LD_CONV3 = 0, 1
+LD_ROWS, LD_CONV3, LD_CONV3_PS = 0, 1, 2
 EP_BF16, EP_GELU, EP_RES, EP_LRELU, EP_PS, EP_IMG, EP_PS_IMG, EP_RES_BF16 = 0, 3, 4, 6, 7, 8, 9, 10
+EP_DGELU, EP_DLRELU, EP_F32_BF16 = 5, 11, 12
 
 UPSAMPLER_PIXELSHUFFLE = 1
 UPSAMPLER_PIXELSHUFFLEDIRECT = 2
@@ -100,6 +101,21 @@ _SIGNATURES = {
     "srk_gemm_ex": (_i, [C.POINTER(GemmArgs), _vp]),
     "srk_mlp_fused_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "srk_img_prep": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, C.POINTER(C.c_float * 3), _vp]),
+    "srk_cab_bwd_workspace": (_sz, [_i, _i, _i]),
+    "srk_cab_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_win256_attention_bwd_scratch": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "srk_win256_attention_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "srk_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srk_add_f32_bf16": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "srk_add_bf16_into_f32": (_i, [_vp, _vp, _i64, _vp]),
+    "srk_add_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "srk_img_grad_prep": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "srk_smallconv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_smallconv_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_stem_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_conv3x3_wgrad_ps_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "srk_mlp_fused_fwd_train": (_i, [_vp] * 15 + [_i, _vp, _i, _i, _vp]),
+    "srk_rowscale_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "srk_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "srk_swin_block_fwd": (_i, [_vp] * 16 + [_f] + [_i] * 8 + [_vp]),
     "srk_win256_attention_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

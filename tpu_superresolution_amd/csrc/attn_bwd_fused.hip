@@ -1,7 +1,8 @@
 // Window attention backward for the classical SwinIR width (C = 180 -> 192, 6 heads x 32) with the q/k/v projection
 // RE-COMPUTED from the saved LayerNorm output and the output-projection dgrad folded in:
 //
-//   q, k, v = xn1_window . Wqkv^T + b  (q scaled)          network_swinir.py:121-124  (what the forward did, bit for bit)
+//   q, k, v = xn1_window . Wqkv^T + b  (q scaled)          network_swinir.py:121-124  (k, v bit for bit what the forward had; q as
+//                                                           fma(x W, scale, b scale): one fp32 rounding instead of two)
 //   dO      = g_window . Wproj                              gradient of :143 (g = d x1 in window order, bf16)
 //   P       = softmax(q k^T + bias + mask)                  :125-139
 //   dV = P^T dO,  dS = P (dP - rowsum(P dP)),  dQ = dS K scale,  dK = dS^T Q,  d(bias) += dS
@@ -21,11 +22,14 @@
 //               softmax, dS; d(bias) accumulated in registers (dense [i][j], 16 VGPRs); dQ^T = K^T dS^T with dS^T taken
 //               straight from the accumulators as the B operand (4 MFMAs); P and dS go to LDS as bf16 [i][j]
 //   phase C     key tile r of head hl: dV^T, dK^T (8 MFMAs, transposing reads of P, dS, dO, Q)
-// Three barriers per window.  The xn1 / g rows of the NEXT window are fetched by LDS-DMA (four 1-KiB pieces per wave) right
-// after the projection's barrier, under phases B and C.  A wave issues exactly three store instructions (dq, dk, dv) between
-// its DMAs and the next window's first barrier, so `s_waitcnt vmcnt(3)` there waits for the DMAs and not for the stores.
+// Three barriers per window.  Two 48 KB row slots alternate between the windows: a window's P / dS tiles overwrite ITS OWN xn1 / g
+// rows once the projection has consumed them, so the other slot is free from the window's first barrier on and the rows of the
+// NEXT window are fetched into it by LDS-DMA (four 1-KiB pieces per wave) under the whole window (projection, phases B and C:
+// with the fetch issued behind the projection only, it had 1.3 us to land and every window waited for it).  A wave issues
+// exactly three store instructions (dq, dk, dv) between its DMAs and the next window's first barrier, so `s_waitcnt vmcnt(3)`
+// there waits for the DMAs and not for the stores.
 //
-// LDS images (151 KB): rows [64][192] bf16 with the 16-byte chunk XOR-swizzled by (row & 7) on the DMA's source address
+// LDS images (148 KB): rows [64][192] bf16 with the 16-byte chunk XOR-swizzled by (row & 7) on the DMA's source address
 // (conflict-free ds_read_b128 B fragments, as gemm_stream.hip); head tiles [64][32] bf16 with chunk ^ tf(row) and P / dS tiles
 // [64][64] bf16 with chunk ^ ps(row), chosen so that the row-fragment ds_read_b128 (lane groups {0-3, 12-15, 20-27} ...),
 // both k orders of ds_read_b64_tr_b16 (32-lane groups) and the MFMA-layout ds_write_b64 hit every bank once (the 8-byte
@@ -39,13 +43,22 @@ constexpr int H_SLOT = 64 * H_K * 2;             // 24 576 B: 64 rows of xn1 or 
 constexpr int H_TILE = 64 * 32;                  // elements of a head tile
 constexpr int H_PT = 64 * 64;                    // elements of a P / dS tile
 constexpr int H_TAB = 225;
-constexpr int OFF_X = 0;
-constexpr int OFF_G = H_SLOT;
-constexpr int OFF_T = 2 * H_SLOT;                // [hl][q, k, v, dO][64][32]
-constexpr int OFF_P = OFF_T + 12 * H_TILE * 2;   // [hl][P, dS][64][64]
-constexpr int OFF_TAB = OFF_P + 6 * H_PT * 2;    // [hl][225] fp32
+constexpr int H_PAIR = 2 * H_SLOT;               // one row slot: xn1 rows | g rows; later [hl][P, dS][64][64] of the same window
+constexpr int OFF_S = 0;                         // two row slots
+constexpr int OFF_T = 2 * H_PAIR;                // [hl][q, k, v, dO][64][32]
+constexpr int OFF_TAB = OFF_T + 12 * H_TILE * 2; // [hl][225] fp32
 constexpr int OFF_PB = OFF_TAB + 2704;           // [hl][q, k, v][32] fp32 projection bias
-constexpr int H_LDS = OFF_PB + 9 * 32 * 4;       // 151 312 B
+constexpr int H_LDS = OFF_PB + 10 * 32 * 4;      // 151 440 B
+static_assert(6 * H_PT * 2 == H_PAIR, "P / dS tiles of a head triple fill a row slot exactly");
+
+#ifdef SRK_PROBE_ABF
+// developer instrumentation (never in the shipped build): s_memrealtime (100 MHz) at the phase boundaries of workgroup 0
+__device__ unsigned long long g_abf_probe[12 * 16 * 8];
+#define ABF_MARK(k) do { if (blockIdx.x == 0 && lane == 0 && t < 16) g_abf_probe[(wave * 16 + t) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int srk_debug_abf_probe(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_abf_probe), sizeof(g_abf_probe)); }
+#else
+#define ABF_MARK(k) do {} while (0)
+#endif
 
 struct BwdFusedParams {
   const bf16_t* xn;      // [B_*64][lda] LayerNorm output, window order
@@ -102,11 +115,9 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
   f32x4_t dbias[4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) dbias[jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float* slab = p.slab + (((long long)gidx * H_NH + head) * 64 + 16 * it + r16) * 64 + 4 * g;
 
   if (nwin > 0) {
     bf16_t* tiles = reinterpret_cast<bf16_t*>(smem + OFF_T);
-    bf16_t* ptiles = reinterpret_cast<bf16_t*>(smem + OFF_P);
     float* tab = reinterpret_cast<float*>(smem + OFF_TAB);
     // rel-pos bias table [3][225] out of the dense [6][64][64]: offset (dy, dx) is realised by the pair i = (max(dy, 0), max(dx, 0)),
     // j = (max(-dy, 0), max(-dx, 0))   (network_swinir.py:89-103)
@@ -130,10 +141,10 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     float* pbs = reinterpret_cast<float*>(smem + OFF_PB);
     for (int i = tid; i < 9 * 32; i += 768) {
       const int tl = i >> 5, hh = tl / 3, which = tl - 3 * hh;
-      pbs[i] = p.bqkv ? p.bqkv[which * H_CA + (3 * tr + hh) * 32 + (i & 31)] : 0.f;
+      pbs[i] = p.bqkv ? p.bqkv[which * H_CA + (3 * tr + hh) * 32 + (i & 31)] * (which == 0 ? p.scale : 1.0f) : 0.f;   // bias * scale
     }
-    const float* pbw = pbs + (hl * 3 + (it < 3 ? it : 0)) * 32 + 4 * g;
-    const float bsel = it < 3 ? 1.0f : 0.0f;
+    for (int i = tid; i < 32; i += 768) pbs[9 * 32 + i] = 0.f;        // the row a dO wave adds
+    const float* pbw = pbs + (it < 3 ? hl * 3 + it : 9) * 32 + 4 * g;
     const float sc = it == 0 ? p.scale : 1.0f;
 
     // ---- DMA: pieces 4 wave .. 4 wave + 3 of the 48 1-KiB pieces (24 of xn1, 24 of g) ------------------------------------------
@@ -141,35 +152,32 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     const bf16_t* dsrc = dma_g ? p.g : p.xn;
     const long long dld = dma_g ? p.ldg : p.lda;
     const int piece0 = dma_g ? 4 * (wave - 6) : 4 * wave;
-    const unsigned ddst = smem_base + (dma_g ? OFF_G : OFF_X) + piece0 * 1024;
-    int doff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = (piece0 + i) * 64 + lane;
-      const int row = q / 24, pos = q - row * 24;
-      doff[i] = row * (int)dld + ((pos ^ (row & 7)) << 3);
-    }
-    auto issue = [&](long long b_) {
+    const unsigned ddst = smem_base + OFF_S + (dma_g ? H_SLOT : 0) + piece0 * 1024;
+    // piece i of this wave covers the 16-byte chunks q = (piece0 + i) 64 + lane of the image: row q / 24, chunk q % 24.  The four
+    // offsets are recomputed per window (a dozen VALU operations) rather than held: the kernel sits at its register limit
+    auto issue = [&](long long b_, int slot) {
       const bf16_t* base = dsrc + b_ * 64 * dld;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) srk_glds16<false>(base + doff[i], __builtin_amdgcn_readfirstlane(ddst + i * 1024));
+      for (int i = 0; i < 4; ++i) {
+        int q = (piece0 + i) * 64 + lane;
+        asm volatile("" : "+v"(q));
+        const int row = (q * 2731) >> 16, pos = q - row * 24;      // q / 24 for q < 1536
+        srk_glds16<false>(base + row * (int)dld + ((pos ^ (row & 7)) << 3), __builtin_amdgcn_readfirstlane(ddst + slot * H_PAIR + i * 1024));
+      }
     };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int s = 0; s < 6; ++s) asm volatile("" ::"v"(wf[j][s]));      // retire the weight loads before the DMA ring starts
     }
-    issue(first);
+    issue(first, 0);
 
     const int tfr = tf(r16), psr = ps(r16);
-    const unsigned char* src = smem + (it < 3 ? OFF_X : OFF_G);
     bf16_t* mytile = tiles + (hl * 4 + it) * H_TILE;
     const bf16_t* Qs = tiles + (hl * 4 + 0) * H_TILE;
     const bf16_t* Ks = tiles + (hl * 4 + 1) * H_TILE;
     const bf16_t* Vs = tiles + (hl * 4 + 2) * H_TILE;
     const bf16_t* Os = tiles + (hl * 4 + 3) * H_TILE;
-    bf16_t* Pb = ptiles + (hl * 2 + 0) * H_PT;
-    bf16_t* Db = ptiles + (hl * 2 + 1) * H_PT;
     // this lane's query i = 16 it + r16; key j = 16 jt + 4 g + e -> table index lane_idx - 30 jt - e (as attn_fused.hip)
     const float* th = tab + hl * H_TAB + ((2 * it + (r16 >> 3)) - (g >> 1) + 7) * 15 + ((r16 & 7) - 4 * (g & 1) + 7) - 93;
     const int ldq = 3 * H_CA;
@@ -184,28 +192,37 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
       const long long b_ = first + t * stride;
       if (t == 0) srk_wait_vmcnt<0>();                    // table / weight loads and the first DMAs
       else srk_wait_vmcnt<3>();                           // everything but this wave's dq / dk / dv stores of window t-1
+      ABF_MARK(0);
       srk_lds_barrier();                                  // A: the rows of window t are in LDS; nobody reads window t-1's tiles
+      ABF_MARK(1);
+      const int cur = (int)(t & 1);
+      if (t + 1 < nwin) issue(b_ + stride, cur ^ 1);      // the other slot held P / dS of window t-1: dead since this barrier
+      const unsigned char* src = smem + OFF_S + cur * H_PAIR + (it < 3 ? 0 : H_SLOT);
+      bf16_t* Pb = reinterpret_cast<bf16_t*>(smem + OFF_S + cur * H_PAIR) + (hl * 2 + 0) * H_PT;
+      bf16_t* Db = Pb + H_PT;
       // ---- projection: this wave's [64][32] tile in four 16-row quarters -----------------------------------------------------
-#pragma unroll 1
+      // (row & 7 == r16 & 7 in every quarter: the swizzled chunk offsets are lane constants, the quarter is an immediate offset)
+      const unsigned char* srow = src + r16 * (H_K * 2);
+      bf16_t* trow = mytile + r16 * 32 + 4 * (g & 1);
+#pragma unroll
       for (int mq = 0; mq < 4; ++mq) {
         f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-        const int row = 16 * mq + r16;
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(src + row * (H_K * 2) + (((s * 4 + g) ^ (row & 7)) << 4));
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(srow + mq * (16 * H_K * 2) + (((s * 4 + g) ^ (r16 & 7)) << 4));
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {    // columns d = 16 j + 4 g .. + 3: chunk 2 j + (g >> 1), half g & 1
+        for (int j = 0; j < 2; ++j) {    // columns d = 16 j + 4 g .. + 3: chunk 2 j + (g >> 1), half g & 1;  (x W + b) scale = x W scale + b scale
           const float4 bq = *reinterpret_cast<const float4*>(pbw + 16 * j);
-          *reinterpret_cast<uint2*>(mytile + row * 32 + (((2 * j + (g >> 1)) ^ tfr) << 3) + 4 * (g & 1)) =
-              pack_bf4((acc[j][0] + bq.x * bsel) * sc, (acc[j][1] + bq.y * bsel) * sc, (acc[j][2] + bq.z * bsel) * sc,
-                       (acc[j][3] + bq.w * bsel) * sc);
+          *reinterpret_cast<uint2*>(trow + mq * (16 * 32) + (((2 * j + (g >> 1)) ^ tfr) << 3)) =
+              pack_bf4(fmaf(acc[j][0], sc, bq.x), fmaf(acc[j][1], sc, bq.y), fmaf(acc[j][2], sc, bq.z), fmaf(acc[j][3], sc, bq.w));
         }
       }
-      srk_lds_barrier();                                  // B: the twelve tiles are complete; the row images are free
-      if (t + 1 < nwin) issue(b_ + stride);
+      ABF_MARK(2);
+      srk_lds_barrier();                                  // B: the twelve tiles are complete; this window's rows are consumed
+      ABF_MARK(3);
 
       // ---- phase B: query tile `it` of head hl against all 64 keys ---------------------------------------------------------------
       {
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
             dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           }
         }
-        const int w = (int)(b_ % p.geom.nW);
+        const int w = (int)((unsigned)b_ % (unsigned)p.geom.nW);      // 32-bit: the launcher bounds B_
         const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
         const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
 #pragma unroll
@@ -285,7 +302,9 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
         store8(row, pack_bf4(aq[0][0] * p.scale, aq[0][1] * p.scale, aq[0][2] * p.scale, aq[0][3] * p.scale),
                pack_bf4(aq[1][0] * p.scale, aq[1][1] * p.scale, aq[1][2] * p.scale, aq[1][3] * p.scale));
       }
+      ABF_MARK(4);
       srk_lds_barrier();                                  // C: P and dS of the three heads are complete
+      ABF_MARK(5);
 
       // ---- phase C: key tile jt = `it` of head hl: dV^T, dK^T summed over all 64 queries ----------------------------------------------
       {
@@ -307,9 +326,11 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
         store8(row + H_CA, pack_bf4(ak[0][0], ak[0][1], ak[0][2], ak[0][3]), pack_bf4(ak[1][0], ak[1][1], ak[1][2], ak[1][3]));
         store8(row + 2 * H_CA, pack_bf4(av[0][0], av[0][1], av[0][2], av[0][3]), pack_bf4(av[1][0], av[1][1], av[1][2], av[1][3]));
       }
+      ABF_MARK(6);
     }
   }
   // partial d(bias) of this workgroup's three heads, dense [i][j]; this wave owns the rows i = 16 it + r16 of head hl
+  float* slab = p.slab + (((long long)gidx * H_NH + head) * 64 + 16 * it + r16) * 64 + 4 * g;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
     *reinterpret_cast<float4*>(slab + 16 * jt) = make_float4(dbias[jt][0], dbias[jt][1], dbias[jt][2], dbias[jt][3]);
@@ -354,7 +375,11 @@ int srk_launch_qkv_attn_bwd(const bf16_t* xn, int lda, const bf16_t* Wqkv, const
     hipFuncAttributes attr;
     configured = -1;
     // a build that spills would put scratch traffic on the counted vmcnt waits: never run it
-    if (hipFuncGetAttributes(&attr, fn) == hipSuccess && attr.localSizeBytes == 0 &&
+#ifdef SRK_PROBE_ABF
+    attr.localSizeBytes = 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS) == hipSuccess) configured = 1;   // instrumented build: spills tolerated
+#endif
+    if (configured < 0 && hipFuncGetAttributes(&attr, fn) == hipSuccess && attr.localSizeBytes == 0 &&
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS) == hipSuccess)
       configured = 1;
   }

@@ -415,6 +415,7 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
   CASE(LD_CONV3, EP_DLRELU)
   CASE(LD_CONV3, EP_F32_BF16)
   CASE(LD_CONV3, EP_GELU)        // first conv of HAT's CAB (hat_arch.py:66-68)
+  CASE(LD_CONV3, EP_DGELU)       // ... and the gradient through it (dgrad of the second conv times gelu'(u))
   CASE(LD_ROWS, EP_RES_BF16)
   CASE(LD_CONV3_PS, EP_BF16)
   CASE(LD_CONV3_PS, EP_DLRELU)

@@ -205,7 +205,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
           const int n = n0 + 64 * c + 4 * j16;
           if (n >= p.N) continue;
           *reinterpret_cast<float4*>(p.outf + (long long)m * p.ldo + n) = v[c];
-          *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v[c].x * f, v[c].y * f, v[c].z * f, v[c].w * f);
+          if (p.outb) *reinterpret_cast<uint2*>(p.outb + (long long)m * p.ldo + n) = pack_bf4(v[c].x * f, v[c].y * f, v[c].z * f, v[c].w * f);
         }
       } else if constexpr (EP == EP_QKV) {
         const long long b_ = m >> 6;

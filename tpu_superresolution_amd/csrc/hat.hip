@@ -209,7 +209,8 @@ int srk_swin_block_fwd(const float* x, float* y, uint16_t* y_bf16, const float* 
 // ---- generic GEMM / implicit-GEMM conv entry -----------------------------------------------------------------------------------
 int srk_gemm_ex(const srk_gemm_args* a, srk_stream_t stream) {
   SRK_REQUIRE(a != nullptr, SRK_E_NULL, "gemm_ex: null argument block");
-  SRK_REQUIRE(a->loader == SRK_LD_ROWS || a->loader == SRK_LD_CONV3, SRK_E_UNSUPPORTED, "gemm_ex: loader %d", a->loader);
+  SRK_REQUIRE(a->loader == SRK_LD_ROWS || a->loader == SRK_LD_CONV3 || a->loader == SRK_LD_CONV3_PS, SRK_E_UNSUPPORTED, "gemm_ex: loader %d",
+              a->loader);
   GemmParams p = {};
   p.A = static_cast<const bf16_t*>(a->A); p.lda = a->lda; p.Wt = static_cast<const bf16_t*>(a->W);
   p.M = a->M; p.N = a->N; p.K = a->K; p.B = a->B; p.H = a->H; p.W = a->Wd; p.CinP = a->CinP; p.r = a->r; p.Cs = a->Cs;
@@ -219,9 +220,18 @@ int srk_gemm_ex(const srk_gemm_args* a, srk_stream_t stream) {
   for (int i = 0; i < 4; ++i) p.mean[i] = a->mean[i];
   p.xn_out = static_cast<bf16_t*>(a->xn_out); p.xn_mean = a->xn_mean; p.xn_rstd = a->xn_rstd; p.xn_gamma = a->xn_gamma;
   p.xn_beta = a->xn_beta; p.xn_C = a->xn_C;
+  p.rowscale = a->rowscale; p.rows_per_sample = a->rows_per_sample;
+  SRK_REQUIRE(a->rowscale == nullptr || (a->epilogue == SRK_EP_RES && a->rows_per_sample > 0), SRK_E_SHAPE,
+              "gemm_ex: rowscale goes with SRK_EP_RES and rows_per_sample > 0");
   p.flops = 2.0 * a->M * (double)a->N * a->K;
   switch (a->epilogue) {
     case SRK_EP_BF16: case SRK_EP_GELU: case SRK_EP_RES: case SRK_EP_LRELU: case SRK_EP_PS: case SRK_EP_IMG: case SRK_EP_PS_IMG: case SRK_EP_RES_BF16:
+      break;
+    case SRK_EP_DGELU: case SRK_EP_DLRELU:
+      SRK_REQUIRE(a->aux != nullptr && a->outb != nullptr, SRK_E_NULL, "gemm_ex: the activation-gradient epilogues need aux and outb");
+      break;
+    case SRK_EP_F32_BF16:
+      SRK_REQUIRE(a->outf != nullptr, SRK_E_NULL, "gemm_ex: SRK_EP_F32_BF16 needs outf");
       break;
     default:
       srk_set_error("gemm_ex: epilogue %d is not exposed", a->epilogue);

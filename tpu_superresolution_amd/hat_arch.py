@@ -17,11 +17,14 @@ stream, nothing else:
     CAB                               two implicit-GEMM 3x3 convs (+GELU), srk_channel_gate, srk_cab_add_ln (+ norm2)
     RHAG conv, conv_after_body, head  implicit-GEMM 3x3 convs with residual / LeakyReLU / PixelShuffle / image epilogues
 
-Scope this round: INFERENCE.  window_size 16 (the attention kernels hold 256 queries per window),
+Scope: inference AND training.  window_size 16 (the attention kernels hold 256 queries per window),
 head_dim <= 32, embed_dim <= 256, upsampler 'pixelshuffle' (the only head the reference's forward implements, :976-985),
-resi_connection '1conv'.  Training (autograd) through this path is not built yet: a grad-enabled forward raises.  No CPU
-fallback: CPU tensors raise.  Weights are packed (bf16, padded, tap-major / pixel-shuffle-permuted) once per parameter
-version on the device.
+resi_connection '1conv'.  A grad-enabled forward is ONE autograd node (``hat_train.HATFunction``): its forward keeps every
+block's activations, its backward is the hand-written backward sequence of ``hat_train.hat_backward`` (256-query window
+attention backward incl. the table gradient through the wrapped relative_position_index_OCA, CAB / channel-attention backward,
+LayerNorm / GELU / conv / linear dgrads and weight gradients); DropPath factors are drawn per block and sample and passed
+to the kernels as data.  No CPU fallback: CPU tensors raise.  Weights are packed (bf16, padded, tap-major / pixel-shuffle-
+permuted) once per parameter version on the device.
 """
 from __future__ import annotations
 
@@ -428,12 +431,21 @@ class HAT(nn.Module):
         why = self._unsupported_reason()
         if why:
             raise SrkUnsupported(f"the MI355X HIP path does not cover {why}; no fallback path exists in this package")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            raise SrkUnsupported("HAT training is not built on the HIP path yet (inference only): call model.eval() / torch.no_grad()")
         p0 = next(self.parameters())
         if p0.device != x.device:
             raise RuntimeError(f"input is on {x.device} but the model is on {p0.device}")
         _lib.claim_device(x.device.index if x.device.index is not None else torch.cuda.current_device())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training (or a grad-enabled eval forward): one autograd node whose backward is the C-ABI backward sequence of
+            # hat_train.py; DropPath factors are drawn here (train mode, hat_arch.py:258) and passed in as data
+            from .hat_train import HATFunction
+            drop = None
+            if self.training:
+                probs = [blk.drop_path_prob for layer in self.layers for blk in layer.residual_group.blocks]
+                if any(pr > 0 for pr in probs):
+                    keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
+                    drop = (torch.rand(len(probs), 2, x.shape[0], device=x.device) < keep).float() / keep
+            return HATFunction.apply(self, x, drop, *[p for _, p in self.named_parameters()])
         with torch.no_grad(), torch.cuda.device(x.device):
             return _hat_forward(self, x.contiguous().float(), self._pack(x.device))
 
@@ -444,7 +456,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _gemm(st, loader, ep, A, W, M, N, K, *, lda=0, conv=None, bias=None, outf=None, outb=None, outb2=None, res=None, ldo=0, scale=0.0,
-          r=0, Cs=0, img=None, xn=None):
+          r=0, Cs=0, img=None, xn=None, aux=None, rowscale=None, rows_per_sample=0):
     a = GemmArgs()
     a.loader, a.epilogue = loader, ep
     a.A, a.lda, a.W, a.M, a.N, a.K = _ptr(A), lda, _ptr(W), M, N, K
@@ -452,6 +464,7 @@ def _gemm(st, loader, ep, A, W, M, N, K, *, lda=0, conv=None, bias=None, outf=No
         a.B, a.H, a.Wd, a.CinP = conv
     a.r, a.Cs = r, Cs
     a.bias, a.outf, a.outb, a.outb2, a.res = _ptr(bias), _ptr(outf), _ptr(outb), _ptr(outb2), _ptr(res)
+    a.aux, a.rowscale, a.rows_per_sample = _ptr(aux), _ptr(rowscale), (rows_per_sample if rowscale is not None else 0)
     a.ldo, a.scale = ldo or N, scale
     if img is not None:
         a.inv_range, a.Cimg, a.Hc, a.Wc = img["inv_range"], img["Cimg"], img["Hc"], img["Wc"]
