@@ -278,6 +278,84 @@ def bench_inference(args):
         dist.destroy_process_group()
 
 
+def bench_hat_train(args):
+    """BASELINE cfg4 as a TRAIN step: HAT-SRx4, 64x64 LR, bs 16 per GPU: forward (activations kept) + L1 +
+    backward (hat_train.hat_backward through the C ABI) + clip 1.0 + AdamW.  The optimizer is torch's (foreach) AdamW on the
+    module's own parameters -- the fused flat-buffer optimizer belongs to the SwinIR engine.  N > 1: per-segment gradient
+    all-reduce on a side stream (distributed.ListGradSynchronizer), overlapped with the backward of the next segment."""
+    import torch.distributed as dist
+    from tpu_superresolution_amd.distributed import ListGradSynchronizer, init_from_env
+    from tpu_superresolution_amd.training import l1_loss_checked
+    rank, world, local = init_from_env("nccl") if args.gpus > 1 else (0, 1, 0)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    model = build_infer_model("cfg4", device).train()
+    if world > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+        model.grad_sync = ListGradSynchronizer()
+        model.grad_sync.time_exposed = True
+    bs = args.batch or 16
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=0.0)
+    torch.manual_seed(1234 + rank)
+    lr_img, hr_img = synthetic_batch(bs, device, seed=1000 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, bad = l1_loss_checked(model(lr_img), hr_img)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return loss, bad
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        loss, bad = step()
+    barrier()
+    if world > 1:
+        model.grad_sync.exposed_ms()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        loss, bad = step()
+        marks[i + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    if int(bad) or not bool(torch.isfinite(loss)):
+        raise SystemExit("non-finite output/loss during the benchmark")
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * bs * HR_PX_PER_SAMPLE * args.steps / elapsed
+        flop_step = 3.0 * bs * INFER["cfg4"]["flop_per_image"]            # fwd + bwd ~ 3 x the reference's forward FLOPs (SURVEY 6)
+        out = {"metric": "HR pixels/sec, HAT x4 train step, 64x64 LR, bs=16/GPU", "value": value, "unit": "HR pixels/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE cfg4 as a train step: HAT-SRx4 (dim 180, 6x6 HAB + 6 OCAB, window 16, overlap 0.5, CAB) fwd + L1 + "
+                                      "bwd + clip 1.0 + AdamW (torch foreach), 64x64 LR -> 256x256 HR, random-init weights, drop_path 0.1",
+                          "batch_per_gpu": bs, "global_batch": bs * world, "parallelism": f"dp{world}", "per_gpu_value": value / world,
+                          "ms_per_step_median": step_ms[len(step_ms) // 2], "step_tflops_per_gpu": flop_step / (ms_per_step * 1e-3) / 1e12,
+                          "final_loss": float(loss)},
+               "roofline": {"bound": "mfma", "kernel": "whole HAT train step", "achieved": flop_step / (ms_per_step * 1e-3) / 1e12,
+                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_step / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                            "traffic": None}}
+        if world > 1:
+            out["dist"] = {"backend": dist.get_backend(), "world_size": world, "buckets": model.grad_sync.buckets_last_step,
+                           "allreduce_exposed_ms": model.grad_sync.exposed_ms()}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def cpu_baseline_infer(name, steps=3):
     spec = INFER[name]
     try:
@@ -325,6 +403,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
+    ap.add_argument("--train", action="store_true", help="cfg4: time a HAT TRAIN step (fwd + L1 + bwd + clip + AdamW) instead of inference")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="developer A/B: srk_set_option(NAME, VALUE) before the model is built (repeatable)")
     args = ap.parse_args()
@@ -338,6 +417,12 @@ def main():
         from tpu_superresolution_amd import _lib as _l
         name, _, value = item.partition("=")
         _l.check(_l.lib().srk_set_option(name.encode(), int(value)))
+    if args.train:
+        if args.config != "cfg4":
+            raise SystemExit("--train selects the HAT train step: use it with --config cfg4 (cfg3, the default, is a train step already)")
+        if args.steps == 10:
+            args.steps = 5
+        return bench_hat_train(args)
     if args.config in INFER:
         return bench_inference(args)
     args.batch = args.batch or 32

@@ -77,3 +77,42 @@ def test_grad_synchronizer_world2_gloo():
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+def _list_worker(rank, world, port, q):
+    """ListGradSynchronizer (the HAT backward's per-segment hook): lists of odd-shaped tensors, several segments per step."""
+    from tpu_superresolution_amd.distributed import ListGradSynchronizer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sync = ListGradSynchronizer(average=True)
+        shapes = [[(3, 4), (7,)], [(2, 2, 3, 3)], [(5,), (1,), (6, 2)]]
+        ok = True
+        for step in range(2):                  # the synchronizer is reused step after step
+            segs = [[torch.full(s, float(rank + 1 + si + step)) for s in seg] for si, seg in enumerate(shapes)]
+            for seg in segs:
+                sync.segment_done(seg + [None])
+            sync.finish()
+            for si, seg in enumerate(segs):
+                want = sum(r + 1 + si + step for r in range(world)) / world
+                ok = ok and all(torch.allclose(t, torch.full_like(t, want)) for t in seg)
+            ok = ok and sync.buckets_last_step == len(shapes)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_list_grad_synchronizer_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_list_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(2))
+    assert results == {0: True, 1: True}

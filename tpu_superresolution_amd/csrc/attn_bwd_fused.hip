@@ -204,15 +204,32 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
       // (row & 7 == r16 & 7 in every quarter: the swizzled chunk offsets are lane constants, the quarter is an immediate offset)
       const unsigned char* srow = src + r16 * (H_K * 2);
       bf16_t* trow = mytile + r16 * 32 + 4 * (g & 1);
+      // The row fragments are requested half a quarter (six MFMAs) ahead of their use, in two register groups of three, fenced so
+      // that the scheduler keeps the order: left to itself the compiler issues each ds_read one or two MFMAs ahead of its use and
+      // every wave then sits through the LDS latency five times per quarter (a whole quarter ahead does not fit the registers).
+      bf16x8_t xq[2][3];
+      auto xload = [&](int mq, int half) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          xq[half][s] = *reinterpret_cast<const bf16x8_t*>(srow + mq * (16 * H_K * 2) + ((((3 * half + s) * 4 + g) ^ (r16 & 7)) << 4));
+      };
+      xload(0, 0);
+      xload(0, 1);
 #pragma unroll
       for (int mq = 0; mq < 4; ++mq) {
         f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(srow + mq * (16 * H_K * 2) + (((s * 4 + g) ^ (r16 & 7)) << 4));
+        for (int half = 0; half < 2; ++half) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+          for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][3 * half + s], xq[half][s], acc[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (mq < 3) xload(mq + 1, half);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {    // columns d = 16 j + 4 g .. + 3: chunk 2 j + (g >> 1), half g & 1;  (x W + b) scale = x W scale + b scale
           const float4 bq = *reinterpret_cast<const float4*>(pbw + 16 * j);
@@ -228,15 +245,25 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
       {
         f32x4_t s[4], dp[4];
         {
+          // all ten fragments first, then the eight MFMAs (fenced: one LDS latency per unit instead of one per MFMA pair)
           const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * it + r16) * 32 + ((g ^ tfr) << 3));
           const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Os + (16 * it + r16) * 32 + ((g ^ tfr) << 3));
+          bf16x8_t kf[4], vf[2];
 #pragma unroll
-          for (int jt = 0; jt < 4; ++jt) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * 32 + ((g ^ tfr) << 3));
-            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + (16 * jt + r16) * 32 + ((g ^ tfr) << 3));
-            s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          }
+          for (int jt = 0; jt < 4; ++jt) kf[jt] = *reinterpret_cast<const bf16x8_t*>(Ks + (16 * jt + r16) * 32 + ((g ^ tfr) << 3));
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) vf[jt] = *reinterpret_cast<const bf16x8_t*>(Vs + (16 * jt + r16) * 32 + ((g ^ tfr) << 3));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) kf[jt] = *reinterpret_cast<const bf16x8_t*>(Vs + (16 * (jt + 2) + r16) * 32 + ((g ^ tfr) << 3));   // v tiles 2, 3
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt], of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) dp[jt + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
         const int w = (int)((unsigned)b_ % (unsigned)p.geom.nW);      // 32-bit: the launcher bounds B_
         const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
@@ -311,17 +338,27 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
         f32x4_t av[2], ak[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) av[dt] = ak[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // every transposing read of the unit first (24 of them, 12 fragments), then the eight MFMAs
+        bf16x8_t pf[2], df[2], otf[2][2], qtf[2][2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
           const int rb0 = 32 * ss + 8 * g, rb1 = rb0 + 4;
-          const bf16x8_t pf = ptile_tr(Pb, rb0, rb1, it, r16);      // P[i][j in tile]   (k = i)
-          const bf16x8_t df = ptile_tr(Db, rb0, rb1, it, r16);      // dS[i][j in tile]  (k = i)
+          pf[ss] = ptile_tr(Pb, rb0, rb1, it, r16);      // P[i][j in tile]   (k = i)
+          df[ss] = ptile_tr(Db, rb0, rb1, it, r16);      // dS[i][j in tile]  (k = i)
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr(Os, rb0, rb1, dt, r16), pf, av[dt], 0, 0, 0);
-            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_tr(Qs, rb0, rb1, dt, r16), df, ak[dt], 0, 0, 0);
+            otf[ss][dt] = tile_tr(Os, rb0, rb1, dt, r16);
+            qtf[ss][dt] = tile_tr(Qs, rb0, rb1, dt, r16);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[ss][dt], pf[ss], av[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[ss][dt], df[ss], ak[dt], 0, 0, 0);
+          }
         bf16_t* row = p.dqkv + (b_ * 64 + 16 * it + r16) * ldq + head * 32 + scol;
         store8(row + H_CA, pack_bf4(ak[0][0], ak[0][1], ak[0][2], ak[0][3]), pack_bf4(ak[1][0], ak[1][1], ak[1][2], ak[1][3]));
         store8(row + 2 * H_CA, pack_bf4(av[0][0], av[0][1], av[0][2], av[0][3]), pack_bf4(av[1][0], av[1][1], av[1][2], av[1][3]));
@@ -330,7 +367,10 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     }
   }
   // partial d(bias) of this workgroup's three heads, dense [i][j]; this wave owns the rows i = 16 it + r16 of head hl
-  float* slab = p.slab + (((long long)gidx * H_NH + head) * 64 + 16 * it + r16) * 64 + 4 * g;
+  // (the lane id is re-derived here: carried across the window loop it would be the one register too many)
+  int lane2;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
+  float* slab = p.slab + (((long long)gidx * H_NH + head) * 64 + 16 * it + (lane2 & 15)) * 64 + 4 * (lane2 >> 4);
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
     *reinterpret_cast<float4*>(slab + 16 * jt) = make_float4(dbias[jt][0], dbias[jt][1], dbias[jt][2], dbias[jt][3]);

@@ -133,6 +133,74 @@ class GradSynchronizer:
         return total / n
 
 
+class ListGradSynchronizer:
+    """Overlapped sum-all-reduce for a model whose backward hands over its parameter gradients as LISTS of tensors, one list per
+    backward segment (HAT: tail, RHAG L-1 .. 0, head -- hat_train.hat_backward's ``hook``).  A segment's tensors are flattened into
+    one bucket on a side stream (event-ordered behind the segment's kernels), all-reduced asynchronously while the next segment's
+    backward kernels run, and copied back (divided by the world size) in ``finish()``, which the backward calls before it returns
+    the gradients to autograd.  Device-agnostic (CPU + gloo for the tests)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, average: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.average = average
+        self._side: Optional[torch.cuda.Stream] = None
+        self._pending = []            # (flat bucket, tensors, work)
+        self.buckets_last_step = 0
+        self.time_exposed = False
+        self._exposed = []
+
+    def segment_done(self, tensors: Sequence[torch.Tensor]) -> None:
+        tensors = [t for t in tensors if t is not None]
+        if self.world == 1 or not tensors:
+            return
+        if tensors[0].is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=tensors[0].device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                flat = torch.cat([t.reshape(-1) for t in tensors])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((flat, tensors, work))
+
+    def finish(self) -> None:
+        timed = self.time_exposed and self._side is not None and self.world > 1
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream())
+        for _, _, w in self._pending:
+            w.wait()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        if timed:
+            ev1.record(torch.cuda.current_stream())
+            self._exposed.append((ev0, ev1))
+        scale = 1.0 / self.world if self.average else 1.0
+        for flat, tensors, _ in self._pending:
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                if scale != 1.0:
+                    t.mul_(scale)
+                off += n
+        self.buckets_last_step = len(self._pending)
+        self._pending.clear()
+
+    def exposed_ms(self) -> Optional[float]:
+        if not self._exposed:
+            return None
+        total = sum(a.elapsed_time(b) for a, b in self._exposed)
+        n = len(self._exposed)
+        self._exposed.clear()
+        return total / n
+
+
 class DataParallelSwinIR:
     """Wraps a SwinIR: identical initial weights on every rank, overlapped gradient all-reduce.
 

@@ -225,19 +225,34 @@ def hat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], drop: Opti
 
 
 # ---- backward -----------------------------------------------------------------------------------------------------------------------
+_ARANGE: Dict[tuple, torch.Tensor] = {}
+
+
+def _arange(n: int, device) -> torch.Tensor:
+    key = (n, str(device))
+    t = _ARANGE.get(key)
+    if t is None:
+        t = _ARANGE[key] = torch.arange(n, device=device)
+    return t
+
+
 def _unpack_linear(dw: torch.Tensor, N: int, K: int, row_map=None, col_map=None) -> torch.Tensor:
-    rows = row_map if row_map is not None else torch.arange(N, device=dw.device)
-    cols = col_map if col_map is not None else torch.arange(K, device=dw.device)
+    if row_map is None and col_map is None:
+        return dw[:N, :K].contiguous()
+    rows = row_map if row_map is not None else _arange(N, dw.device)
+    cols = col_map if col_map is not None else _arange(K, dw.device)
     return dw[rows[:, None], cols[None, :]].contiguous()
 
 
 def _unpack_conv(dw: torch.Tensor, Cout: int, Cin: int, CinP: int, row_map=None) -> torch.Tensor:
-    rows = row_map if row_map is not None else torch.arange(Cout, device=dw.device)
-    return dw.view(dw.shape[0], 9, CinP)[rows][:, :, :Cin].reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
+    v = dw.view(dw.shape[0], 9, CinP)
+    v = v[:Cout] if row_map is None else v[row_map]
+    return v[:, :, :Cin].reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
 
 
-def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """-> {parameter name: gradient} for every parameter of the model."""
+def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Tensor]:
+    """-> {parameter name: gradient} for every parameter of the model.  hook (distributed.ListGradSynchronizer or None): gets the
+    gradient tensors of each finished segment (tail, every RHAG, head) so that their all-reduce overlaps the next segment."""
     ha = _ha()
     _gemm, _rup, _ptr = ha._gemm, ha._rup, ha._ptr
     P = m._pack(dy.device)
@@ -256,6 +271,13 @@ def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
     drop = S["drop"]
     G: Dict[str, torch.Tensor] = {}
     names = {id(p): n for n, p in m.named_parameters()}
+    handed = set()
+
+    def segment_done():
+        if hook is not None:
+            fresh = [k for k in G if k not in handed]
+            handed.update(fresh)
+            hook.segment_done([G[k] for k in fresh])
 
     def pname(p):
         return names[id(p)]
@@ -266,7 +288,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
         N, K = lin.weight.shape
         G[pname(lin.weight)] = _unpack_linear(dw, N, K, row_map, col_map)
         if lin.bias is not None:
-            G[pname(lin.bias)] = db[row_map if row_map is not None else torch.arange(N, device=dev)].contiguous()
+            G[pname(lin.bias)] = (db[:N] if row_map is None else db[row_map]).contiguous()
 
     def conv_wgrad(dyb, xb, conv, Bc, Hc, Wc, CinP, NP, r=1, row_map=None):
         dw = torch.zeros(NP, 9 * CinP, **f32)
@@ -278,7 +300,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
             check(L.srk_conv3x3_wgrad_ps_bf16(dyb.data_ptr(), xb.data_ptr(), dw.data_ptr(), db.data_ptr(), Bc, Hc, Wc, CinP, NP, r, 64, st))
         Cout, Cin_ = conv.weight.shape[:2]
         G[pname(conv.weight)] = _unpack_conv(dw, Cout, Cin_, CinP, row_map)
-        G[pname(conv.bias)] = db[row_map if row_map is not None else torch.arange(Cout, device=dev)].contiguous()
+        G[pname(conv.bias)] = (db[:Cout] if row_map is None else db[row_map]).contiguous()
 
     def ln_bwd(dyb, x, mean, rstd, norm, gx, gxb, accumulate):
         dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
@@ -327,6 +349,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
     gx = torch.empty(T, CP, **f32)        # gradient of the current layer's OUTPUT (later: of its input)
     gxb = torch.empty(T, CP, **b16)
     ln_bwd(dxn, S["x_last"], S["meanf"], S["rstdf"], m.norm, gx, gxb, accumulate=False)
+    segment_done()
 
     # ---------------- layers, last to first ----------------
     blocks = S["blocks"]
@@ -405,6 +428,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
             ln_bwd(dxn1, bk["x_in"], bk["mean1"], bk["rstd1"], blk.norm1, gx2, gxb2, accumulate=True)
         # layer skip: d(layer input) = d(body input) + d(layer output)
         check(L.srk_add_f32_bf16(gx.data_ptr(), gx2.data_ptr(), gxb.data_ptr(), T * CP, st))
+        segment_done()
 
     # ---------------- head: patch_embed.norm, long skip, conv_first ----------------
     gf = torch.empty(T, CP, **f32)
@@ -413,6 +437,9 @@ def hat_backward(m, S: dict, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
     dwf, dbf = torch.zeros_like(m.conv_first.weight, dtype=torch.float32), torch.zeros_like(m.conv_first.bias, dtype=torch.float32)
     check(L.srk_stem_wgrad(S["img4"].data_ptr(), gf.data_ptr(), dwf.data_ptr(), dbf.data_ptr(), B, H, W, Cin, C_, CP, st))
     G[pname(m.conv_first.weight)], G[pname(m.conv_first.bias)] = dwf, dbf
+    segment_done()
+    if hook is not None:
+        hook.finish()
     return G
 
 
@@ -431,7 +458,7 @@ class HATFunction(torch.autograd.Function):
     def backward(ctx, dy):
         model = ctx.model
         with torch.cuda.device(dy.device):
-            G = hat_backward(model, ctx.saved, dy.contiguous().float())
+            G = hat_backward(model, ctx.saved, dy.contiguous().float(), hook=getattr(model, "grad_sync", None))
         ctx.saved = None
         grads = []
         for n, p in model.named_parameters():
