@@ -120,6 +120,8 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   "block_light" 1 (default) / 0: SwinIR-light width (C <= 64, 6 heads x d <= 16, hidden <= 128), inference: each Swin block is
  *   ONE kernel (csrc/block_light.hip: LayerNorms, qkv, window attention, proj, MLP and both residuals of a window in LDS and
  *   registers) or the layer-per-launch path.
+ *   "mlp_bwd_fused" 1 (default) / 0: the MLP half of a Swin block's backward as one kernel (csrc/gemm_stream.hip: fc2 dgrad, GELU',
+ *   fc1 dgrad and the norm2 backward; d u stays on the CU between the two GEMMs) or the two streaming GEMMs.
  *   "attn_bwd_fused" 1 (default) / 0: attention backward with q/k/v re-projected from the saved norm1 output and the output-
  *   projection dgrad folded in (csrc/attn_bwd_fused.hip; classical width; the training forward then stores no q/k/v), or the
  *   dgrad GEMM + csrc/attn.hip on q/k/v saved by the forward.  Read when a training forward lays out its workspace.

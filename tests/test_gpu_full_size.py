@@ -111,3 +111,36 @@ def test_gradients_add_up_over_an_uneven_batch_split(cfg3, split):
         worst = max(worst, rel)
     # each run rounds its own bf16 activation-gradient stream: the sums agree to bf16-noise level, not bit for bit
     assert worst <= 1.5e-2, worst
+
+
+def test_fused_backward_kernels_vs_the_separate_ones(cfg3):
+    """Round-3 backward fusions A/B-pinned in process (srk_set_option): the re-projecting attention backward (attn_bwd_fused:
+    q/k/v recomputed from xn1, proj dgrad folded in, no q/k/v stored by the forward) and the fused MLP backward (mlp_bwd_fused:
+    fc2 dgrad, GELU', fc1 dgrad and norm2 backward in one kernel) against the kernels they replace -- same math, different fp32
+    summation order and bf16 flips downstream -- with DropPath factors active, at a batch that fills the persistent grids."""
+    from tpu_superresolution_amd._lib import check, lib
+    cfg, sd = cfg3
+    x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(31)).cuda()
+    t = torch.rand(8, 3, 256, 256, generator=torch.Generator().manual_seed(32)).cuda()
+    ds = ((torch.rand(36, 2, 8, generator=torch.Generator().manual_seed(33)) < 0.85).float() / 0.85).cuda()
+
+    def grads(attn_fused, mlp_fused):
+        check(lib().srk_set_option(b"attn_bwd_fused", attn_fused))
+        check(lib().srk_set_option(b"mlp_bwd_fused", mlp_fused))
+        try:
+            m = build(cfg, sd, train=True, drop_path_rate=0.1)
+            loss = torch.nn.functional.l1_loss(m(x, drop_scale=ds), t)
+            loss.backward()
+            return float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        finally:
+            check(lib().srk_set_option(b"attn_bwd_fused", 1))
+            check(lib().srk_set_option(b"mlp_bwd_fused", 1))
+
+    l_ref, g_ref = grads(0, 0)
+    for a, b in ((1, 0), (0, 1), (1, 1)):
+        l, g = grads(a, b)
+        assert abs(l - l_ref) <= 1e-6 * abs(l_ref)                 # the forward differs only in what it stores
+        rels = {n: float((g[n] - g_ref[n]).norm() / (g_ref[n].norm() + 1e-20)) for n in g_ref}
+        worst = max(rels, key=rels.get)
+        assert rels[worst] <= 2e-2, (a, b, worst, rels[worst])
+        assert float(np.median(list(rels.values()))) <= 5e-3, (a, b, float(np.median(list(rels.values()))))

@@ -289,6 +289,10 @@ int srk_set_option(const char* name, int value) {
     srk_block_light_enable(value);
     return SRK_OK;
   }
+  if (strcmp(name, "mlp_bwd_fused") == 0) {
+    srk_mlp_bwd_fused_enable(value);
+    return SRK_OK;
+  }
   if (strcmp(name, "mlp_fused") == 0) {
     srk_mlp_fused_enable(value);
     return SRK_OK;

@@ -98,3 +98,7 @@ void srk_gemm_stream_tune(int bm, int ks2, int split, int nb);   // 0 / -1 / -1 
 // the 16 x 384 hidden tile stays in LDS.  C = 180 (192 padded), hidden 360 (384).  SRK_NOT_COVERED -> run fc1 / fc2 separately.
 int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream);
 void srk_mlp_fused_enable(int on);
+// ... and its backward: d u = (d x2 . W2) * gelu'(u) stays in LDS between the two dgrads, the LayerNorm (norm2) backward rides in the
+// second one's epilogue.  A = d x2, Wt = W2^T, aux = u, u_out = d u (output), W2 = W1^T, HP = 384 + the EP_LNBWD fields.
+int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream);
+void srk_mlp_bwd_fused_enable(int on);

@@ -947,7 +947,264 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(const GemmParams p, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused MLP backward (the mirror of mlp_fused_fwd_kernel):
+//   dh  = d x2 . W2            d u = dh * gelu'(u)                         (network_swinir.py:25-28 Mlp.forward backwards)
+//   dxn = d u . W1             LayerNorm(norm2) backward of dxn on x1 -> gx += ..., bf16 copy (window order, DropPath factor)
+// Run separately (EP_DGELU GEMM, then the EP_LNBWD GEMM) d u makes a round trip through HBM (100 MB written, 100 MB read back
+// per block at cfg3); here it is written once -- the fc1 weight gradient reads it -- and consumed from LDS.
+//
+// One persistent 512-thread workgroup per CU walks 16-row tiles; both weight matrices live in registers: the FRONT waves (4-7)
+// each hold a 96-column slice of W2^T [384][192] (6 x 6 fragments), the BACK waves (0-3) a 48-column slice of W1^T [192][384]
+// over K = 384 (3 x 12 fragments).  The row operands arrive by LDS-DMA through TWO rings, because the tile's operands are
+// consumed two iterations apart: the front ring (3 slots: d x2 rows + the u rows, 18 KB) feeds iteration i, the back ring
+// (2 slots: x1 rows, gradient-stream rows, row statistics / maps, 25.5 KB) feeds the LayerNorm-backward epilogue in iteration
+// i + 2.  The front waves issue both (front tile i + 2 behind barrier A, back tile i behind barrier B) and never store, so
+// their counted vmcnt wait -- everything but the youngest front tile and the youngest back tile -- is exact.  Per iteration:
+//   front  MFMA of tile i, d u = acc * gelu'(u) in the MFMA register layout (u read from the slot's swizzled image) -> Ds[i & 1]
+//   back   LayerNorm-backward row epilogue of tile i - 2 (T2 + its back slot), MFMA of tile i - 1 from Ds, the d u rows of tile
+//          i - 1 to global (768-byte rows), accumulators -> T2 behind barrier B
+// Same MFMA order and rounding points as the separate kernels.
+struct MlpBwdCfg {
+  using CB = StreamCfg<EP_LNBWD, 0, 16>;                    // back slot: two fp32 row operands + row scalars / maps, no A image
+  static constexpr int BM = 16, K1 = 192, HP = 384, RF = 3, RB = 2;
+  static constexpr int A_BYTES = BM * K1 * 2;               // 6 144
+  static constexpr int U_BYTES = BM * HP * 2;               // 12 288
+  static constexpr int FSLOT = A_BYTES + U_BYTES;           // 18 432
+  static constexpr int PF = 2 + 3;                          // DMA instructions per front wave and front tile (A: 96 pieces, u: 192)
+  static constexpr int PB = CB::P;                          // ... and back tile (3 + 3 + 1)
+  static constexpr int T2_OFF = 0;
+  static constexpr int RED_OFF = CB::T_BYTES;               // dgamma / dbeta column partials, one private [2][192] per back wave
+  static constexpr int GAM_OFF = RED_OFF + 4 * 2 * SBN * 4; // gamma of norm2, zero-padded [192] (W1 fills the back waves' registers)
+  static constexpr int DS_OFF = GAM_OFF + SBN * 4;          // Ds[2]: d u tiles (swizzled A-operand layout of the second GEMM)
+  static constexpr int FS_OFF = DS_OFF + 2 * U_BYTES;
+  static constexpr int BS_OFF = FS_OFF + RF * FSLOT;
+  static constexpr int LDS = BS_OFF + RB * CB::SLOT;
+  static_assert(CB::A_BYTES == 0 && CB::NI_A == 0, "back slot carries no A image");
+  static_assert(LDS <= LDS_BUDGET, "fused MLP backward: LDS budget");
+  static_assert(PF + PB <= 63, "vmcnt overflow");
+};
+
+__global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(const GemmParams p, int groups_per_xcd) {
+  using M = MlpBwdCfg;
+  using CB = M::CB;
+  constexpr int BM = M::BM;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  float* T2 = reinterpret_cast<float*>(smem + M::T2_OFF);
+  float* colred = reinterpret_cast<float*>(smem + M::RED_OFF);
+  unsigned char* Ds = smem + M::DS_OFF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, gx = blockIdx.x >> 3;
+  if (gx >= groups_per_xcd) return;
+  const int Gm = 8 * groups_per_xcd, gi = gx * 8 + xcd;
+  const int ntm = p.M / BM;
+  const int nt = gi < ntm ? (ntm - gi + Gm - 1) / Gm : 0;
+  if (nt == 0) return;
+  float* gam = reinterpret_cast<float*>(smem + M::GAM_OFF);
+  for (int i = tid; i < 4 * 2 * SBN; i += 512) colred[i] = 0.f;
+  for (int i = tid; i < SBN; i += 512) gam[i] = i < p.ln_C ? p.ln_gamma[i] : 0.f;
+  __syncthreads();
+
+  if (wave >= 4) {
+    // =================================== front waves: both DMA rings + dh + gelu' ===================
+    const int lw = wave - 4;
+    bf16x8_t wf[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int s = 0; s < 6; ++s)
+        wf[j][s] = *reinterpret_cast<const bf16x8_t*>(p.Wt + (long long)(lw * 96 + 16 * j + r16) * M::K1 + s * 32 + g * 8);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int s = 0; s < 6; ++s) asm volatile("" ::"v"(wf[j][s]));     // retire the loads before the DMA rings start
+
+    // front tile: this wave's quarter of the A image (96 16-byte pieces: 2 instructions) and of the u image (192 pieces: 3)
+    int aoff[2], uoff[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qq = lw * 96 + i * 64 + lane;
+      const int row = qq / 24, pos = qq - row * 24;
+      aoff[i] = row * p.lda + ((pos ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int qq = lw * 192 + i * 64 + lane;
+      const int row = qq / 48, pos = qq - row * 48;
+      uoff[i] = row * p.HP + ((pos ^ (row & 7)) << 3);
+    }
+    auto issue_front = [&](int t) {
+      const long long m0 = (long long)(gi + t * Gm) * BM;
+      const unsigned slot = smem_base + M::FS_OFF + (t % M::RF) * M::FSLOT;
+      const bf16_t* ab = p.A + m0 * p.lda;
+      const bf16_t* ub = p.aux + m0 * p.HP;
+      glds16(ab + aoff[0], __builtin_amdgcn_readfirstlane(slot + (lw * 96) * 16));
+      // (the second A instruction is half empty -- 96 pieces per wave -- but still one instruction on vmcnt)
+      if (lane < 32) glds16(ab + aoff[1], __builtin_amdgcn_readfirstlane(slot + (lw * 96 + 64) * 16));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) glds16(ub + uoff[i], __builtin_amdgcn_readfirstlane(slot + M::A_BYTES + (lw * 192 + i * 64) * 16));
+    };
+    IssueState<EP_LNBWD, 0, BM> is;
+    issue_init<EP_LNBWD, 0, BM>(p, 0, lw, lane, is);
+    auto issue_back = [&](int t) {
+      stream_issue_tile<EP_LNBWD, 0, BM>(p, is, (gi + t * Gm) * BM, 0, smem_base + M::BS_OFF + (t % M::RB) * CB::SLOT, lw, lane, smem, smem_base);
+    };
+
+    for (int s = 0; s < M::RF - 1 && s < nt; ++s) issue_front(s);
+    for (int i = 0; i < nt + 2; ++i) {
+      // landed before A(i): front tile i and back tile i - 2; younger and still allowed in flight: front tile i + 1, back tile i - 1
+      if (i + 1 < nt && i >= 1) wait_vmcnt<M::PF + M::PB>();
+      else if (i + 1 < nt) wait_vmcnt<M::PF>();
+      else wait_vmcnt<0>();
+      lds_barrier();                                            // A(i)
+      if (i < nt) {
+        if (i + M::RF - 1 < nt) issue_front(i + M::RF - 1);     // its slot held tile i - 1, consumed before B(i - 1)
+        const unsigned char* slot = smem + M::FS_OFF + (i % M::RF) * M::FSLOT;
+        const unsigned char* uimg = slot + M::A_BYTES;
+        f32x4_t acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(slot + r16 * (M::K1 * 2) + (((s * 4 + g) ^ (r16 & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf, acc[j], 0, 0, 0);
+        }
+        // lane holds dh[row r16][n .. n+3], n = 96 lw + 16 j + 4 g  ->  times gelu'(u) -> bf16 into this tile's Ds
+        unsigned char* ds = Ds + (i & 1) * M::U_BYTES;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int n = lw * 96 + 16 * j + 4 * g;               // 16-byte chunk n / 8, half (n & 4)
+          const int off = r16 * (M::HP * 2) + ((((n >> 3) ^ (r16 & 7)) << 4) | ((n & 4) << 1));
+          const uint2 ua = *reinterpret_cast<const uint2*>(uimg + off);
+          float u0, u1, u2, u3;
+          unpack_bf2(ua.x, u0, u1);
+          unpack_bf2(ua.y, u2, u3);
+          *reinterpret_cast<uint2*>(ds + off) = dgelu_mul_pack4(acc[j][0], acc[j][1], acc[j][2], acc[j][3], u0, u1, u2, u3);
+        }
+      }
+      lds_barrier();                                            // B(i)
+      if (i < nt) issue_back(i);                                // its slot held tile i - 2, whose epilogue ran before B(i)
+    }
+  } else {
+    // =================================== back waves: d u . W1 + LayerNorm backward + d u stores =====
+    const int wn = wave;
+    bf16x8_t w2[3][12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < 12; ++s)
+        w2[j][s] = *reinterpret_cast<const bf16x8_t*>(p.W2 + (long long)(wn * 48 + 16 * j + r16) * M::HP + s * 32 + g * 8);
+    const int btid = tid;        // 0..255
+    const int sub = lane >> 4, j16 = lane & 15, lr = wave * 4 + sub;     // row epilogue: 16 lanes per row, 4 rows per wave
+    const float invC = 1.0f / (float)p.ln_C;
+    const bool has_scale = p.rowscale != nullptr;
+    for (int i = 0; i < nt + 2; ++i) {
+      lds_barrier();                                            // A(i)
+      if (i >= 2) {                                             // LayerNorm-backward epilogue of tile i-2 (T2 holds it since B(i-1))
+        // (the EP_LNBWD row epilogue of stream_epilogue_tile with gamma and the dgamma / dbeta partials in LDS instead of registers)
+        const int t = i - 2;
+        const unsigned char* slot = smem + M::BS_OFF + (t % M::RB) * CB::SLOT;
+        const float* auxf = reinterpret_cast<const float*>(slot + 2 * CB::E32_BYTES);
+        const int* maps = reinterpret_cast<const int*>(auxf + 4 * 64);
+        const long long t_ = maps[lr], ro = maps[64 + lr];
+        const float mean = auxf[lr], rstd = auxf[64 + lr];
+        const float f = has_scale ? auxf[128 + lr] : 1.0f;
+        float dy[NC][4], xh[NC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 dv = *reinterpret_cast<const float4*>(T2 + lr * SBNP + 64 * c + 4 * j16);
+          const float4 xv = *reinterpret_cast<const float4*>(slot + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+          const float4 gv = *reinterpret_cast<const float4*>(gam + 64 * c + 4 * j16);
+          const float dvs[4] = {dv.x, dv.y, dv.z, dv.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dy[c][e] = dvs[e];
+            xh[c][e] = 64 * c + 4 * j16 + e < p.ln_C ? (xs[e] - mean) * rstd : 0.f;
+            const float dg = dvs[e] * gs[e];
+            s1 += dg;
+            s2 += dg * xh[c][e];
+          }
+        }
+        s1 = wave_sum16(s1) * invC;
+        s2 = wave_sum16(s2) * invC;
+        // dgamma / dbeta: the wave's four rows are summed across its 16-lane groups (two permlane swaps), then the first group adds
+        // them to the wave's private partial in LDS with plain read-modify-write (LDS float atomics -- 24 per lane and tile, four
+        // lanes per address -- made this kernel 2.4 x slower than the two kernels it replaces)
+        float* myred = colred + wave * (2 * SBN);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 old = *reinterpret_cast<const float4*>(slot + CB::E32_BYTES + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
+          const float4 gv = *reinterpret_cast<const float4*>(gam + 64 * c + 4 * j16);
+          const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+          float o[4] = {old.x, old.y, old.z, old.w};
+          float pg[4], pb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool live = 64 * c + 4 * j16 + e < p.ln_C;     // xh and gamma are zero in the pad columns; dy need not be
+            o[e] += live ? rstd * (dy[c][e] * gs[e] - s1 - xh[c][e] * s2) : 0.f;
+            pg[e] = xrow_sum4(dy[c][e] * xh[c][e]);
+            pb[e] = xrow_sum4(live ? dy[c][e] : 0.f);
+          }
+          if (sub == 0) {
+            float4* rg = reinterpret_cast<float4*>(myred + 64 * c + 4 * j16);
+            float4* rb = reinterpret_cast<float4*>(myred + SBN + 64 * c + 4 * j16);
+            const float4 a = *rg, b = *rb;
+            *rg = make_float4(a.x + pg[0], a.y + pg[1], a.z + pg[2], a.w + pg[3]);
+            *rb = make_float4(b.x + pb[0], b.y + pb[1], b.z + pb[2], b.w + pb[3]);
+          }
+          st_f4(p.outf + t_ * p.ldo + 64 * c + 4 * j16, make_float4(o[0], o[1], o[2], o[3]));
+          if (p.outb) st_u2(p.outb + ro * p.ldo + 64 * c + 4 * j16, pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f));
+        }
+      }
+      f32x4_t acc[3];
+      const bool have = i >= 1 && i - 1 < nt;
+      if (have) {                                               // d u . W1 of tile i-1 from Ds
+        const unsigned char* ds = Ds + ((i - 1) & 1) * M::U_BYTES;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+          const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(ds + r16 * (M::HP * 2) + (((s * 4 + g) ^ (r16 & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[j][s], xf, acc[j], 0, 0, 0);
+        }
+        {                                                       // d u rows leave the CU once (the fc1 weight gradient reads them)
+          const long long m0 = (long long)(gi + (i - 1) * Gm) * BM;
+          int bt = btid;
+          asm volatile("" : "+v"(bt));                          // recompute the chunk map per tile: W1 owns the registers
+#pragma unroll 1
+          for (int it = 0; it < 3; ++it) {
+            const int idx = it * 256 + bt;                      // 16 rows x 48 chunks
+            const int row = idx / 48, c = idx - row * 48;
+            const uint4 dv = *reinterpret_cast<const uint4*>(ds + row * (M::HP * 2) + ((c ^ (row & 7)) << 4));
+            *reinterpret_cast<uint4*>(p.u_out + (m0 + row) * p.HP + c * 8) = dv;
+          }
+        }
+      }
+      lds_barrier();                                            // B(i): T2's readers (epilogue of tile i-2) are done
+      if (have) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          *reinterpret_cast<float4*>(T2 + r16 * SBNP + wn * 48 + 16 * j + 4 * g) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      }
+    }
+  }
+  // dgamma / dbeta: one global atomic per column per workgroup
+  lds_barrier();
+  for (int n = tid; n < p.ln_C; n += 512) {
+    atomicAdd(p.ln_dgamma + n, (colred[n] + colred[2 * SBN + n]) + (colred[4 * SBN + n] + colred[6 * SBN + n]));
+    atomicAdd(p.ln_dbeta + n, (colred[SBN + n] + colred[3 * SBN + n]) + (colred[5 * SBN + n] + colred[7 * SBN + n]));
+  }
+}
+
 int g_mlp_fused_enabled = 1;
+int g_mlp_bwd_fused_enabled = 1;
 
 int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
 int g_num_cus = 0;
@@ -1137,4 +1394,38 @@ int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(g_num_cus), dim3(512), MlpCfg::LDS, stream, p, g_num_cus / 8);
   srk_probe_post(FAM_GEMM_LINEAR, stream);
   return srk_check_launch("mlp_fused");
+}
+
+void srk_mlp_bwd_fused_enable(int on) { g_mlp_bwd_fused_enabled = on ? 1 : 0; }
+
+// A = d x2 bf16 [M][lda], Wt = W2^T [384][192], aux = u [M][HP], u_out = d u [M][HP] (written), W2 = W1^T [192][384]; the
+// LayerNorm-backward fields, outf / outb / geom / rowscale as for EP_LNBWD.  SRK_NOT_COVERED -> run the two GEMMs.
+int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream) {
+  if (!g_mlp_bwd_fused_enabled) return SRK_NOT_COVERED;
+  if (g_stream_enabled < 0) {
+    const char* e = getenv("SRK_GEMM_STREAM");
+    g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_stream_enabled) return SRK_NOT_COVERED;
+  if (g_num_cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    g_num_cus = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount & ~7;
+  }
+  if (g_num_cus < 8) return SRK_NOT_COVERED;
+  if (p.K != MlpBwdCfg::K1 || p.HP != MlpBwdCfg::HP || p.N != SBN || p.lda % 8 != 0 || p.ldo != SBN) return SRK_NOT_COVERED;
+  if (p.M % 64 != 0 || p.M < 64 * g_num_cus || p.M >= (1 << 24)) return SRK_NOT_COVERED;
+  if (p.rowscale && (p.rows_per_sample <= 0 || p.rows_per_sample % 64 != 0)) return SRK_NOT_COVERED;
+  if (!p.A || !p.Wt || !p.W2 || !p.aux || !p.u_out || !p.outf || !p.ln_x || !p.ln_mean || !p.ln_rstd || !p.ln_gamma || !p.ln_dgamma ||
+      !p.ln_dbeta || p.ln_rows_window != 0)
+    return SRK_NOT_COVERED;
+  static int configured = 0;
+  const int rc = stream_configure(&mlp_fused_bwd_kernel, MlpBwdCfg::LDS, &configured);
+  if (rc) return rc;
+  if (configured < 0) return SRK_NOT_COVERED;       // the build spilled: never run it (scratch traffic would break the counted waits)
+  srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
+  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(g_num_cus), dim3(512), MlpBwdCfg::LDS, stream, p, g_num_cus / 8);
+  srk_probe_post(FAM_GEMM_LINEAR, stream);
+  return srk_check_launch("mlp_fused_bwd");
 }

@@ -1159,7 +1159,23 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         const WinGeom geom = make_wgeom(H, W, bw.shift);
         const float* ds_attn = drop_scale ? drop_scale + ((size_t)bi * 2 + 0) * B : nullptr;
         const float* ds_prev_mlp = (drop_scale && j > 0) ? drop_scale + ((size_t)(bi - 1) * 2 + 1) * B : nullptr;
-        {  // d h = d x2 . Wfc2 ; d u = d h * gelu'(u)
+        // MLP half as one kernel where it applies: d u = (d x2 . Wfc2) * gelu'(u) stays on the CU, d xn2 = d u . Wfc1 with LN2 backward
+        // in its epilogue (gx2 += dx1, gxbw = bf16(gx2 * f_attn) in window order); d u is written once for the fc1 weight gradient
+        int rc_mlpb = SRK_NOT_COVERED;
+        if (fuse_ln) {
+          GemmParams g = {};
+          g.A = c.at<bf16_t>(w.gxb2); g.lda = CP; g.Wt = c.packed + bw.Wfc2T; g.K = CP; g.HP = HP; g.aux = c.at<bf16_t>(ba.u);
+          g.u_out = c.at<bf16_t>(w.du); g.W2 = c.packed + bw.Wfc1T; g.M = T; g.N = CP; g.ldo = CP;
+          g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(w.gxbw); g.geom = geom; g.rowscale = ds_attn; g.rows_per_sample = HW;
+          g.ln_x = c.at<float>(ba.x1); g.ln_mean = c.at<float>(ba.mean2); g.ln_rstd = c.at<float>(ba.rstd2);
+          g.ln_gamma = params + bw.n2w; g.ln_dgamma = grads + bw.n2w; g.ln_dbeta = grads + bw.n2b; g.ln_C = C;
+          g.ln_rows_window = 0; g.ln_stats_by_m = 0; g.ln_out_window = 1;
+          g.flops = 2.0 * fl_mlp;
+          g.bytes = (double)T * (2.0 * C + 2.0 * p->HID + 2.0 * p->HID + 4.0 * C + 8.0 * C + 2.0 * C) + 4.0 * C * p->HID;   // d x2, u in; d u out; x1, gx in; gx, gxbw out
+          rc_mlpb = srk_launch_mlp_fused_bwd(g, st);
+          if (rc_mlpb != SRK_NOT_COVERED) RUN(rc_mlpb);
+        }
+        if (rc_mlpb == SRK_NOT_COVERED) {  // d h = d x2 . Wfc2 ; d u = d h * gelu'(u)
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.gxb2); g.lda = CP; g.Wt = c.packed + bw.Wfc2T; g.M = T; g.N = HP; g.K = CP;
           g.outb = c.at<bf16_t>(w.du); g.aux = c.at<bf16_t>(ba.u); g.ldo = HP; g.flops = fl_mlp;
@@ -1168,7 +1184,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         }
         WgradParams wq[4];   // the four weight gradients of the block go out as one launch (before gxb2 is overwritten)
         wq[0] = lin_wgrad(c, c.at<bf16_t>(w.gxb2), CP, c.at<bf16_t>(ba.h), HP, T, bw.Wfc2, bw.bfc2, fl_mlp);
-        {  // d xn2 = d u . Wfc1
+        if (rc_mlpb == SRK_NOT_COVERED) {  // d xn2 = d u . Wfc1
           GemmParams g = {};
           g.A = c.at<bf16_t>(w.du); g.lda = HP; g.Wt = c.packed + bw.Wfc1T; g.M = T; g.N = CP; g.K = HP;
           g.ldo = CP; g.flops = fl_mlp;
@@ -1185,7 +1201,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           }
         }
         wq[1] = lin_wgrad(c, c.at<bf16_t>(w.du), HP, c.at<bf16_t>(ba.xn2), CP, T, bw.Wfc1, bw.bfc1, fl_mlp);
-        if (!fuse_ln) {
+        if (!fuse_ln && rc_mlpb == SRK_NOT_COVERED) {
           // LN2 backward, iterated in window order; emits the (DropPath-scaled) bf16 gradient of x1 in window order
           RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.dxn), c.at<float>(ba.x1), c.at<float>(ba.mean2), c.at<float>(ba.rstd2),
                                 params + bw.n2w, c.at<float>(w.gx2), c.at<bf16_t>(w.gxbw), grads + bw.n2w, grads + bw.n2b, T, C, CP,
