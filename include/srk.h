@@ -367,6 +367,12 @@ typedef struct {
   float mean[3];         /* (0.4488, 0.4371, 0.4040) for 3-channel input, 0 otherwise (:658-662) */
   float qk_scale;        /* <= 0: head_dim ** -0.5 */
   int resi_connection;   /* SRK_RESI_* */
+  int use_checkpoint;    /* constructor use_checkpoint (network_swinir.py:397-405 wraps every block in torch.utils.checkpoint): != 0 ->
+                            a training forward keeps, per block, only what cannot be recomputed cheaply (norm1 / norm2 outputs, the
+                            residual rows, statistics); the attention output and the MLP's u / h = gelu(u) live in ONE shared set of
+                            buffers and the backward pass re-runs the block's fused attention-forward and MLP-forward kernels to refill
+                            them (same kernels, same inputs: gradients are bit-identical to use_checkpoint = 0; -250 MB per block at
+                            cfg3 bs 32, + two forward launches per block in backward) */
 } srk_swinir_config;
 
 typedef struct srk_swinir_plan srk_swinir_plan;

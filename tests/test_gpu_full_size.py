@@ -144,3 +144,32 @@ def test_fused_backward_kernels_vs_the_separate_ones(cfg3):
         worst = max(rels, key=rels.get)
         assert rels[worst] <= 2e-2, (a, b, worst, rels[worst])
         assert float(np.median(list(rels.values()))) <= 5e-3, (a, b, float(np.median(list(rels.values()))))
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_use_checkpoint_recomputes_and_gives_the_same_gradients(cfg3, batch):
+    """use_checkpoint=True (network_swinir.py:397-405): the training executor keeps ao / u / h in ONE shared buffer set and the
+    backward pass re-runs the block's forward kernels to refill them -- the same kernels on the same inputs, so the gradients are
+    those of use_checkpoint=False up to the fp32 atomics of the small reductions; the training workspace shrinks by 250 MB per
+    block at cfg3 bs 32.  batch 1 runs the tile-GEMM fallbacks (fewer tokens than the persistent grids need), batch 8 the
+    streaming / fused kernels."""
+    import tpu_superresolution_amd as T
+    cfg, sd = cfg3
+    x = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(41)).cuda()
+    t = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(42)).cuda()
+    ds = ((torch.rand(36, 2, batch, generator=torch.Generator().manual_seed(43)) < 0.85).float() / 0.85).cuda()
+    out = {}
+    for ck in (False, True):
+        m = T.SwinIR(drop_path_rate=0.1, use_checkpoint=ck, **cfg.kwargs())
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        loss = torch.nn.functional.l1_loss(m(x, drop_scale=ds), t)
+        loss.backward()
+        out[ck] = (float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()}, m._engine.workspace.numel())
+    assert out[True][0] == out[False][0]
+    for n, g in out[False][1].items():
+        rel = float((out[True][1][n] - g).norm() / (g.norm() + 1e-20))
+        assert rel <= 1e-5, (n, rel)
+    T_tok = batch * 64 * 64
+    saved = out[False][2] - out[True][2]
+    assert saved >= 35 * T_tok * (192 + 384 + 384) * 2 * 0.95, (out[False][2], out[True][2])       # 35 of 36 ao + u + h sets, minus the scratch row buffer

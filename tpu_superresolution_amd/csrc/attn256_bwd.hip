@@ -12,7 +12,11 @@
 // One 256-thread workgroup per (window, head) holds K, V (NK rows), Q and dO (256 rows) of the window in LDS and makes two passes:
 //   pass 1 (a wave owns 64 queries, 16 at a time; lane = query, registers = keys -- the forward's layout): S^T and dP^T, softmax,
 //          row statistics (max, 1/sum, rowsum(P dP)) to LDS, dS; dq^T = K^T dS^T with dS^T taken from the accumulators as the B
-//          operand; d table: one LDS float atomic per (query, key) into the head's table-gradient column;
+//          operand; d table: self-attention: the query row qy and the key row ky of a (query tile, key tile) pair are constants,
+//          so dS is first summed in REGISTERS per row offset qy - ky (19 offsets per wave x 16 x 16 column pairs: 76 VGPRs) and only
+//          those sums are scattered along their column offsets with LDS float atomics at the end of the pass (LDS float atomics are
+//          slow on this part: one per (query, key) pair -- 65 536 per workgroup -- took 2/3 of the kernel); the overlapping form
+//          (24-wide key rows: a key tile straddles two rows) still adds every pair;
 //   pass 2 (a wave owns every fourth 16-key tile; lane = key, registers = queries): S and dP recomputed per pair of query tiles,
 //          P and dS rebuilt from the saved row statistics (no cross-lane reduction), dV^T += dO^T P, dK^T += Q^T dS.
 // Self-attention windows partition the tokens: dk / dv are stored.  Overlapping key windows share tokens (up to four windows per
@@ -26,7 +30,18 @@
 
 namespace {
 
-constexpr int BP = 40;      // LDS row pitch (elements) of the [rows][32] tiles (as attn256.hip)
+// LDS layout of the [rows][32] bf16 tiles.  Overlapping form: row pitch 40 elements (as attn256.hip: 16-byte fragment reads of 16
+// consecutive rows hit 64 distinct banks).  Self-attention: unpadded 64-byte rows with the 16-byte chunk XOR-swizzled by tfs(row) --
+// the swizzle of attn_bwd_fused.hip, conflict-free for the row-fragment and both transposing read patterns -- so that the four
+// tiles take 64 KB (76 KB with the statistics and table columns: room for a second workgroup per CU once the pass-1 register
+// footprint -- ~380 with the 76 row-offset sums -- fits 256; until then the kernel runs one workgroup per CU).
+template <bool PAD>
+struct TileAddr {
+  static constexpr int PITCH = PAD ? 40 : 32;
+  static __device__ __forceinline__ int tfs(int r) { return ((((r >> 2) ^ (r >> 3)) & 1) << 1) | (((r >> 3) ^ (r >> 1)) & 1); }
+  // element offset of 16-byte chunk c (0..3) of row r
+  static __device__ __forceinline__ int chunk(int r, int c) { return PAD ? r * 40 + c * 8 : r * 32 + ((c ^ tfs(r)) << 3); }
+};
 
 struct Win256BwdParams {
   const bf16_t* qkv;    // [T][ldq]
@@ -48,14 +63,21 @@ __device__ __forceinline__ int region3(int v, int n, int w, int s) { return v < 
 __device__ __forceinline__ bf16x8_t b_cat4(bf16x4_t lo, bf16x4_t hi) {
   return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-// transposed fragment in accumulator k order (slots (g, jj): rows k0 + 4 g + jj, jj < 4, and k0 + 16 + 4 g + jj - 4)
+// transposed fragment in accumulator k order (slots (g, jj): rows k0 + 4 g + jj, jj < 4, and k0 + 16 + 4 g + jj - 4), columns
+// c0 .. c0 + 15 (c0 = 0 or 16): the lane supplies the address of row rb + (ll >> 2), columns c0 + 4 (ll & 3) ..
+template <bool PAD>
 __device__ __forceinline__ bf16x8_t tr_acc(const bf16_t* tile, int k0, int c0, int lane) {
-  const int g = lane >> 4;
-  return b_cat4(lds_tr_read(tr_addr(tile, BP, k0 + 4 * g, c0, lane)), lds_tr_read(tr_addr(tile, BP, k0 + 16 + 4 * g, c0, lane)));
+  const int g = lane >> 4, ll = lane & 15;
+  const int ra = k0 + 4 * g + (ll >> 2), rb = ra + 16;
+  const int c = (c0 >> 3) + ((ll & 3) >> 1), in = (ll & 1) << 2;
+  return b_cat4(lds_tr_read(tile + TileAddr<PAD>::chunk(ra, c) + in), lds_tr_read(tile + TileAddr<PAD>::chunk(rb, c) + in));
 }
 
 template <int NT, bool OCA>        // NT = key tiles of 16 (16: 256 keys, 36: 576 keys)
 __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256BwdParams p) {
+  using TA = TileAddr<OCA>;
+  constexpr int BP = TA::PITCH;
+  constexpr int TABN = OCA ? 1536 : 964;                 // floats reserved per table column (1521 / 961 rows)
   constexpr int NK = NT * 16;
   constexpr int KW = OCA ? 24 : 16;
   constexpr int PAD = OCA ? 4 : 0;
@@ -67,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
   bf16_t* Os = Qs + 256 * BP;                            // [256][BP]
   float* stats = reinterpret_cast<float*>(Os + 256 * BP);   // [256][4]: max * log2e, 1 / sum, rowsum(P dP)
   float* tab = stats + 256 * 4;                          // [table_rows]
-  float* tabg = tab + 1536;                              // [table_rows] gradient
+  float* tabg = tab + TABN;                              // [table_rows] gradient
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int h = blockIdx.x % p.nH;
@@ -118,8 +140,8 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<uint4*>(Ks + kk * BP + 8 * c) = kv[c];
-      *reinterpret_cast<uint4*>(Vs + kk * BP + 8 * c) = vv[c];
+      *reinterpret_cast<uint4*>(Ks + TA::chunk(kk, c)) = kv[c];
+      *reinterpret_cast<uint4*>(Vs + TA::chunk(kk, c)) = vv[c];
     }
   }
   {
@@ -128,8 +150,8 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
     const bf16_t* orow = p.dout + t * p.ldo + h * 32;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<uint4*>(Qs + tid * BP + 8 * c) = *reinterpret_cast<const uint4*>(qrow + 8 * c);
-      *reinterpret_cast<uint4*>(Os + tid * BP + 8 * c) = *reinterpret_cast<const uint4*>(orow + 8 * c);
+      *reinterpret_cast<uint4*>(Qs + TA::chunk(tid, c)) = *reinterpret_cast<const uint4*>(qrow + 8 * c);
+      *reinterpret_cast<uint4*>(Os + TA::chunk(tid, c)) = *reinterpret_cast<const uint4*>(orow + 8 * c);
     }
   }
   for (int i = tid; i < p.table_rows; i += 256) {
@@ -155,22 +177,31 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
   };
 
   // =========================== pass 1: lane = query r16 of the tile, registers = keys 16 j + 4 g + e ===========================
-#pragma unroll 1
+  // self-attention: dsum[qt - j + 15][e] = sum of dS[(qy, qx = r16)][(ky = j, kx = 4 g + e)] over this wave's pairs with qy - ky =
+  // 4 wave + qt - j  (qt and j are unrolled: the index is a constant)
+  constexpr int NDY = OCA ? 1 : 19;
+  float dsum[NDY][4];
+#pragma unroll
+  for (int d = 0; d < NDY; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dsum[d][e] = 0.f;
+  constexpr int QT_UNROLL = OCA ? 1 : 4;
+#pragma unroll QT_UNROLL
   for (int qt = 0; qt < 4; ++qt) {
     const int ql = wave * 64 + qt * 16 + r16;
     const int qy = ql >> 4, qx = ql & 15;
     const int qlab = need_mask ? label(qy, qx) : 0;
-    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + ql * BP + 8 * g);
-    const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Os + ql * BP + 8 * g);
+    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + TA::chunk(ql, g));
+    const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Os + TA::chunk(ql, g));
     // the 36-tile form cannot hold S^T and dP^T at once (2 x 144 registers): dP^T tiles are produced twice, where they are used
     f32x4_t s[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (16 * j + r16) * BP + 8 * g);
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + TA::chunk(16 * j + r16, g));
       s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     auto dp_tile = [&](int j) {
-      const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + (16 * j + r16) * BP + 8 * g);
+      const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + TA::chunk(16 * j + r16, g));
       return __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     };
     float mx = -3.0e38f;
@@ -223,13 +254,14 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ds[e] = s[j][e] * (dpj[e] - dl);                                     // dS
-          atomicAdd(&tabg[rpi(qy, qx, ky, kx0 + e)], ds[e]);                   // d table[rpi] (LDS)
+          if constexpr (OCA) atomicAdd(&tabg[rpi(qy, qx, ky, kx0 + e)], ds[e]);   // d table[rpi] (LDS)
+          else dsum[OCA ? 0 : qt - j + 15][e] += ds[e];
         }
         lohi[u] = pack_bf4(ds[0], ds[1], ds[2], ds[3]);
       }
       const bf16x8_t dsf = __builtin_bit_cast(bf16x8_t, make_uint4(lohi[0].x, lohi[0].y, lohi[1].x, lohi[1].y));
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) aq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_acc(Ks, 32 * jj, 16 * dt, lane), dsf, aq[dt], 0, 0, 0);
+      for (int dt = 0; dt < 2; ++dt) aq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_acc<OCA>(Ks, 32 * jj, 16 * dt, lane), dsf, aq[dt], 0, 0, 0);
     }
     // aq[dt][e] = dq[query r16][d = 16 dt + 4 g + e]
     bf16_t* qdst = p.dqkv + q_token(ql) * p.ldq + h * 32;
@@ -237,6 +269,16 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
     for (int dt = 0; dt < 2; ++dt)
       *reinterpret_cast<uint2*>(qdst + 16 * dt + 4 * g) =
           pack_bf4(aq[dt][0] * p.scale, aq[dt][1] * p.scale, aq[dt][2] * p.scale, aq[dt][3] * p.scale);
+  }
+  if constexpr (!OCA) {
+    // rows qy - ky = 4 wave + d - 15 of the table gradient: column offset qx - kx = r16 - 4 g - e
+#pragma unroll
+    for (int d = 0; d < NDY; ++d) {
+      const int dyv = 4 * wave + d - 15;                    // in -15 .. 15 for the pairs that exist
+      if (dyv < -15 || dyv > 15) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&tabg[(dyv + 15) * 31 + (r16 - 4 * g - e + 15)], dsum[d][e]);
+    }
   }
   __syncthreads();      // row statistics of all 256 queries and every d table add are in LDS
 
@@ -246,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
     const int kl = 16 * j + r16;
     const int ky = kl / KW, kx = kl - ky * KW;
     const int klab = need_mask ? label(ky, kx) : 0;
-    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + kl * BP + 8 * g);
-    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + kl * BP + 8 * g);
+    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + TA::chunk(kl, g));
+    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + TA::chunk(kl, g));
     f32x4_t av[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     f32x4_t ak[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 2
@@ -256,8 +298,8 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * qp + u;                                           // = qy of every query of the tile (16-wide windows)
-        const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * qt + r16) * BP + 8 * g);
-        const bf16x8_t oa = *reinterpret_cast<const bf16x8_t*>(Os + (16 * qt + r16) * BP + 8 * g);
+        const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + TA::chunk(16 * qt + r16, g));
+        const bf16x8_t oa = *reinterpret_cast<const bf16x8_t*>(Os + TA::chunk(16 * qt + r16, g));
         // sa[e] = q . k of (query 16 qt + 4 g + e, key kl);  da[e] = dO . v of the same pair
         const f32x4_t sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const f32x4_t da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, vf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -279,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
       const bf16x8_t dfb = __builtin_bit_cast(bf16x8_t, make_uint4(dl2[0].x, dl2[0].y, dl2[1].x, dl2[1].y));
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_acc(Os, 32 * qp, 16 * dt, lane), pfb, av[dt], 0, 0, 0);
-        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_acc(Qs, 32 * qp, 16 * dt, lane), dfb, ak[dt], 0, 0, 0);
+        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_acc<OCA>(Os, 32 * qp, 16 * dt, lane), pfb, av[dt], 0, 0, 0);
+        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_acc<OCA>(Qs, 32 * qp, 16 * dt, lane), dfb, ak[dt], 0, 0, 0);
       }
     }
     // av[dt][e] = dv[key kl][d = 16 dt + 4 g + e], ak likewise (dk = scale dS^T q)
@@ -335,7 +377,8 @@ __global__ __launch_bounds__(256) void win256_dkv_cast_kernel(const float* __res
 
 template <int NT, bool OCA>
 int launch_bwd(const Win256BwdParams& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(2 * NT * 16 + 512) * BP * sizeof(bf16_t) + 256 * 4 * sizeof(float) + 2 * 1536 * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * NT * 16 + 512) * TileAddr<OCA>::PITCH * sizeof(bf16_t) + 256 * 4 * sizeof(float) +
+                         2 * (OCA ? 1536 : 964) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_bwd_kernel<NT, OCA>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -56,6 +56,8 @@ struct BlockAct {
 struct Workspace {
   int B = 0, H0 = 0, W0 = 0, H = 0, W = 0, training = 0;
   int attn_recompute = 0;      // training: the attention backward re-projects q/k/v (attn_bwd_fused.hip); the forward stores none
+  int ckpt = 0;                // training with use_checkpoint: ao / u / h of all blocks share one buffer set, refilled in backward
+  size_t ck_x = 0;             // ... scratch for the re-run MLP forward's residual output (discarded)
   int opt_sig = 0;             // option values the layout depends on
   long long T = 0;
   size_t img4, f0, x0, mean_pe, rstd_pe;
@@ -239,6 +241,7 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
   w.W = (W0 + 7) / 8 * 8;
   w.T = (long long)B * w.H * w.W;
   w.opt_sig = layout_option_sig();
+  w.ckpt = (training != 0 && p->cfg.use_checkpoint != 0) ? 1 : 0;
   w.attn_recompute = training != 0 && srk_attn_fused_mode() != 0;   // the forward that stores no q/k/v is the fused one
   for (const BlockW& b : p->blocks)
     if (srk_qkv_attn_bwd_slabs(w.T / 64, b.nH, b.CA, p->CP) == 0) w.attn_recompute = 0;
@@ -260,6 +263,13 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
   size_t pingP = 0, pingQ = 0, shared_xb = 0;
   size_t maxCA = 0;
   for (const BlockW& b : p->blocks) maxCA = b.CA > (int)maxCA ? b.CA : maxCA;
+  size_t ck_ao = 0, ck_u = 0, ck_h = 0;
+  if (w.ckpt) {
+    ck_ao = a.get("ck.ao", T * maxCA * 2);
+    ck_u = a.get("ck.u", T * HP * 2);
+    ck_h = a.get("ck.h", T * HP * 2);
+    w.ck_x = a.get("ck.x", T * CP * 4);
+  }
   if (!training) {
     shared.xn1w = a.get("xn1w", T * CP * 2);
     shared.mean1 = a.get("mean1", T * 4);
@@ -291,13 +301,13 @@ void layout_workspace(const srk_swinir_plan* p, Workspace& w, int B, int H0, int
         ba.mean1 = a.get(pre + "mean1", T * 4);
         ba.rstd1 = a.get(pre + "rstd1", T * 4);
         ba.qkv = w.attn_recompute ? 0 : a.get(pre + "qkv", T * 3 * bw.CA * 2);
-        ba.ao = a.get(pre + "ao", T * bw.CA * 2);
+        ba.ao = w.ckpt ? ck_ao : a.get(pre + "ao", T * bw.CA * 2);
         ba.x1 = a.get(pre + "x1", T * CP * 4);
         ba.xn2 = a.get(pre + "xn2", T * CP * 2);
         ba.mean2 = a.get(pre + "mean2", T * 4);
         ba.rstd2 = a.get(pre + "rstd2", T * 4);
-        ba.u = a.get(pre + "u", T * HP * 2);
-        ba.h = a.get(pre + "h", T * HP * 2);
+        ba.u = w.ckpt ? ck_u : a.get(pre + "u", T * HP * 2);
+        ba.h = w.ckpt ? ck_h : a.get(pre + "h", T * HP * 2);
         ba.x_out = a.get(pre + "x_out", T * CP * 4);
       } else {
         const size_t xin = ba.x_in;
@@ -795,8 +805,8 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
         }
         GemmParams gf = g;    // fused: the hidden tile never leaves the CU between the two layers
         gf.A = g1.A; gf.lda = CP; gf.Wt = g1.Wt; gf.K = CP; gf.bias = g1.bias; gf.W2 = g.Wt; gf.bias2 = g.bias; gf.HP = HP;
-        gf.u_out = w.training ? c.at<bf16_t>(ba.u) : nullptr;
-        gf.h_out = w.training ? c.at<bf16_t>(ba.h) : nullptr;
+        gf.u_out = (w.training && !w.ckpt) ? c.at<bf16_t>(ba.u) : nullptr;      // use_checkpoint: refilled by the backward pass
+        gf.h_out = (w.training && !w.ckpt) ? c.at<bf16_t>(ba.h) : nullptr;
         gf.flops = 2.0 * fl_mlp;
         gf.bytes = (double)T * (2.0 * C + 4.0 * C + 4.0 * C + 2.0 * C + (w.training ? 4.0 * p->HID : 0.0)) + 4.0 * C * p->HID;   // xn2, x1 in; x2, xb | xn1 (, u, h) out
         const int rc_mlp = srk_launch_mlp_fused(gf, st);
@@ -1159,6 +1169,19 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         const WinGeom geom = make_wgeom(H, W, bw.shift);
         const float* ds_attn = drop_scale ? drop_scale + ((size_t)bi * 2 + 0) * B : nullptr;
         const float* ds_prev_mlp = (drop_scale && j > 0) ? drop_scale + ((size_t)(bi - 1) * 2 + 1) * B : nullptr;
+        if (w.ckpt) {
+          // use_checkpoint: refill the shared u / h (fc1 + GELU of the saved norm2 output) and ao (fused qkv + attention forward of
+          // the saved norm1 output) buffers of this block -- the same kernels on the same inputs as in the forward pass
+          GemmParams g1 = {};
+          g1.A = c.at<bf16_t>(ba.xn2); g1.lda = CP; g1.Wt = c.packed + bw.Wfc1; g1.M = T; g1.N = HP; g1.K = CP;
+          g1.bias = c.side + bw.bfc1; g1.outb = c.at<bf16_t>(ba.u); g1.outb2 = c.at<bf16_t>(ba.h); g1.ldo = HP; g1.flops = fl_mlp;
+          g1.bytes = (double)T * (2.0 * C + 4.0 * p->HID) + 2.0 * C * p->HID;
+          RUN(srk_launch_gemm(LD_ROWS, EP_GELU, g1, st));
+          const int rc_f = srk_launch_qkv_attn_fwd(c.at<bf16_t>(ba.xn1w), CP, c.packed + bw.Wqkv, c.side + bw.bqkv, bw.scale, nullptr,
+                                                   c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, bw.CA, CP, geom, st);
+          if (rc_f == SRK_NOT_COVERED) RUN(srk_launch_attn_fwd(c.at<bf16_t>(ba.qkv), c.side + bw.biasd, c.at<bf16_t>(ba.ao), T / 64, bw.nH, geom, st));
+          else RUN(rc_f);
+        }
         // MLP half as one kernel where it applies: d u = (d x2 . Wfc2) * gelu'(u) stays on the CU, d xn2 = d u . Wfc1 with LN2 backward
         // in its epilogue (gx2 += dx1, gxbw = bf16(gx2 * f_attn) in window order); d u is written once for the fc1 weight gradient
         int rc_mlpb = SRK_NOT_COVERED;

@@ -215,6 +215,7 @@ class SwinIR(nn.Module):
         self.num_layers, self.ape, self.patch_norm, self.mlp_ratio = len(depths), ape, patch_norm, mlp_ratio
         self.qkv_bias, self.qk_scale, self.resi_connection, self.patch_size = qkv_bias, qk_scale, resi_connection, patch_size
         self.drop_rate, self.attn_drop_rate, self.drop_path_rate = drop_rate, attn_drop_rate, drop_path_rate
+        self.use_checkpoint = bool(use_checkpoint)       # recompute policy of the training executor (include/srk.h: use_checkpoint)
         self.mean = torch.Tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1) if in_chans == 3 else torch.zeros(1, 1, 1, 1)
 
         self.conv_first = nn.Conv2d(in_chans, embed_dim, 3, 1, 1)
@@ -338,7 +339,8 @@ class SwinIR(nn.Module):
             self._plan = SwinIRPlan(img_size=min(self.patches_resolution), in_chans=self.in_chans, embed_dim=self.embed_dim,
                                     depths=self.depths, num_heads=self.heads, window_size=self.window_size,
                                     mlp_ratio=self.mlp_ratio, upscale=self.upscale, img_range=self.img_range,
-                                    upsampler=self.upsampler, qk_scale=self.qk_scale, resi_connection=self.resi_connection)
+                                    upsampler=self.upsampler, qk_scale=self.qk_scale, resi_connection=self.resi_connection,
+                                    use_checkpoint=self.use_checkpoint)
         eng = SwinIREngine(self._plan, device)
         named = dict(self.named_parameters())
         missing = [p.name for p in self._plan.params if p.name not in named]
