@@ -264,6 +264,13 @@ int srk_stem_conv(const float* img4, const float* weight, const float* bias, flo
  * (16 x 16 queries, 24 x 24 zero-padded keys, NK = 576). */
 int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* bias, int table_rows, uint16_t* out, int ldo, int B, int H,
                              int W, int wh, int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap, srk_stream_t stream);
+/* The same with the H x W map zero-padded at the bottom / right to an Hp x Wp window frame (DAT: Adaptive_Spatial_Attention.forward
+ * dat_arch.py:376-384 pads q, k, v to a multiple of the larger split; windows, cyclic shift and shift mask live on the frame, a padded
+ * token is a zero vector that takes part in its window's softmax with score = bias, padded output rows are dropped) and with
+ * windows of 256 OR 128 tokens (wh * ww; 128: split_size [8, 16], dense bias [num_heads][128][128]).  Hp, Wp multiples of wh, ww. */
+int srk_win_attention_fwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, int table_rows, uint16_t* out, int ldo, int B, int H,
+                                 int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap,
+                                 srk_stream_t stream);
 /* ChannelAttention gate of CAB (:41-57): gate[b][c] = out_scale * sigmoid(W2 relu(W1 mean_b + b1) + b2), mean over the HW tokens
  * of x bf16 [B*HW][CP]; w1 [S][C], w2 [C][S] fp32 (the 1x1 convs).  workspace: srk_channel_gate_workspace bytes. */
 size_t srk_channel_gate_workspace(int B, int HW, int CP);

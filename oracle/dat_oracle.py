@@ -139,30 +139,39 @@ def _spatial_interaction(img: Tensor, sd, pre: str) -> Tensor:
 
 
 def adaptive_spatial_attention(x: Tensor, H: int, W: int, sd, pre: str, cfg: DATConfig, nH: int, shifted: bool) -> Tensor:
+    """dat_arch.py:366-446.  q, k, v are zero-padded at the bottom / right to a multiple of the larger split (:376-384): the windows,
+    the cyclic shift and the shift mask live on the padded _H x _W frame; a padded token is a zero vector that takes part in its
+    window's softmax with score = bias, and the padded rows of the result are cropped (:409-410, :415-416)."""
     B, L, C = x.shape
     s0, s1 = cfg.split_size
-    if H % max(s0, s1) or W % max(s0, s1):
-        raise ValueError("oracle: H, W must be multiples of the larger split size (the reference zero-pads q/k/v otherwise)")
+    big = max(s0, s1)
+    Hp, Wp = (H + big - 1) // big * big, (W + big - 1) // big * big
     q, k, v = F.linear(x, sd[pre + "qkv.weight"], sd.get(pre + "qkv.bias")).chunk(3, dim=-1)
+
+    def padded(t):       # [B, L, C] -> [B, Hp * Wp, C]
+        if Hp == H and Wp == W:
+            return t
+        return F.pad(t.reshape(B, H, W, C), (0, 0, 0, Wp - W, 0, Hp - H)).reshape(B, Hp * Wp, C)
+    qp, kp, vp = padded(q), padded(k), padded(v)
     scale = cfg.qk_scale or (C // 2 // (nH // 2)) ** -0.5
     outs = []
     for br, (hs, wsz, sy, sx) in enumerate(((s0, s1, s0 // 2, s1 // 2), (s1, s0, s1 // 2, s0 // 2))):
         if not shifted:
             sy = sx = 0
         sl = slice(br * C // 2, (br + 1) * C // 2)
-        idx = torch.from_numpy(rect_window_token_index(H, W, hs, wsz, sy, sx))
+        idx = torch.from_numpy(rect_window_token_index(Hp, Wp, hs, wsz, sy, sx))
         nW, N = idx.shape
         hh = nH // 2
 
         def win(t):
             return t[:, :, sl][:, idx.reshape(-1)].reshape(B * nW, N, hh, C // 2 // hh).permute(0, 2, 1, 3)
-        attn = (win(q) * scale) @ win(k).transpose(-2, -1) + dynamic_pos_bias(sd, f"{pre}attns.{br}.pos.", hs, wsz)[None]
+        attn = (win(qp) * scale) @ win(kp).transpose(-2, -1) + dynamic_pos_bias(sd, f"{pre}attns.{br}.pos.", hs, wsz)[None]
         if shifted:
-            attn = (attn.reshape(B, nW, hh, N, N) + torch.from_numpy(rect_shift_mask(H, W, hs, wsz, sy, sx))[None, :, None]).reshape(-1, hh, N, N)
-        o = (attn.softmax(-1) @ win(v)).transpose(1, 2).reshape(B, nW * N, C // 2)
-        merged = torch.zeros(B, L, C // 2, dtype=x.dtype)
+            attn = (attn.reshape(B, nW, hh, N, N) + torch.from_numpy(rect_shift_mask(Hp, Wp, hs, wsz, sy, sx))[None, :, None]).reshape(-1, hh, N, N)
+        o = (attn.softmax(-1) @ win(vp)).transpose(1, 2).reshape(B, nW * N, C // 2)
+        merged = torch.zeros(B, Hp * Wp, C // 2, dtype=x.dtype)
         merged[:, idx.reshape(-1)] = o
-        outs.append(merged)
+        outs.append(merged.reshape(B, Hp, Wp, C // 2)[:, :H, :W].reshape(B, L, C // 2))
     att = torch.cat(outs, dim=2)
     conv = _dwconv_bn_gelu(v.transpose(1, 2).reshape(B, C, H, W), sd, pre)
     cmap = _channel_interaction(conv, sd, pre).reshape(B, 1, C)

@@ -179,6 +179,44 @@ DAT_TINY = dict(img_size=32, in_chans=3, embed_dim=48, split_size=(8, 32), depth
                 upscale=2, img_range=1.0, resi_connection="1conv", upsampler="pixelshuffle")
 
 
+DAT_TINY_816 = dict(img_size=32, in_chans=3, embed_dim=48, split_size=(8, 16), depth=(3, 2), num_heads=(4, 4), expansion_factor=2.0,
+                    upscale=2, img_range=1.0, resi_connection="1conv", upsampler="pixelshuffle")
+
+
+def gen_g14b():
+    """G14b: DAT with the reference's zero padding of q / k / v (input sizes that are not multiples of the larger split:
+    dat_arch.py:376-384 + the on-the-fly masks of :404-407) and with 128-token windows -- split_size [8, 16], expansion_factor 2,
+    the configuration the reference's own __main__ instantiates (dat_arch.py:862-883)."""
+    from oracle import dat_oracle as DO
+    da = import_reference("dat_arch")
+    arrays = {}
+    for tag, base in (("s832", DAT_TINY), ("s816", DAT_TINY_816)):
+        cfg = DO.DATConfig(**base)
+        sd = DO.random_state_dict(cfg, seed=15, scale=2.0)
+        torch.manual_seed(0)
+        m = da.DAT(**cfg.kwargs())
+        assert list(m.state_dict().keys()) == list(sd.keys())
+        for k in sd:
+            if k.endswith(("rpe_biases", "relative_position_index", "attn_mask_0", "attn_mask_1")):
+                assert torch.equal(m.state_dict()[k].to(sd[k].dtype), sd[k]), k
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        arrays[f"{tag}.weight_sha1"] = np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()])))
+        sizes = ((24, 40), (48, 64), (32, 32)) if tag == "s832" else ((32, 32), (24, 40), (40, 16))
+        for hw in sizes:
+            x = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(hw[0] * 100 + hw[1] + 7))
+            with torch.no_grad():
+                y = m(x)
+            arrays[f"{tag}.x_{hw[0]}x{hw[1]}"] = x.numpy()
+            arrays[f"{tag}.y_{hw[0]}x{hw[1]}"] = y.numpy()
+        xt = torch.randn(1, 24 * 40, 48, generator=torch.Generator().manual_seed(9))
+        with torch.no_grad():
+            arrays[f"{tag}.blk_shifted_24x40"] = m.layers[0].blocks[2](xt, (24, 40)).numpy()      # shifted spatial block on a padded frame
+            arrays[f"{tag}.blk_plain_24x40"] = m.layers[0].blocks[0](xt, (24, 40)).numpy()
+    arrays["weight_seed"], arrays["weight_scale"], arrays["blk_seed"] = np.array(15), np.array(2.0), np.array(9)
+    save("g14b_dat_pad_split", **arrays)
+
+
 def gen_g14():
     """G14: DAT (dat_arch.py imports with the timm stand-in).  Index tables bit-exact, a tiny DAT end to end (eval: BatchNorm with
     running statistics) incl. a shifted spatial block (rg 0, b 2), a channel-attention block and both window orientations, the
@@ -249,9 +287,12 @@ def main():
         return gen_g11()
     if "--only-g13" in sys.argv:
         return gen_g13()
+    if "--only-g14b" in sys.argv:
+        return gen_g14b()
     gen_g11()
     gen_g13()
     gen_g14()
+    gen_g14b()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------

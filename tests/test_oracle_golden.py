@@ -348,3 +348,40 @@ def test_g14_dat_cfg5_schema_and_probe():
     assert tuple(y.shape) == tuple(g["shape"])
     assert np.abs(y.reshape(-1)[g["probe_index"]] - g["probe_value"]).max() < 2e-5
     assert abs(float(y.mean()) - float(g["mean"])) < 1e-5 and abs(float(y.std()) - float(g["std"])) < 1e-5
+
+
+# ---- G14b: DAT with padded frames (sizes that are not multiples of the larger split) and split_size [8, 16] ---------------------------
+DAT_TINY_816 = dict(DAT_TINY, split_size=(8, 16))
+
+
+def dat_g14b_weights(tag):
+    from oracle import dat_oracle as DO
+    g = load_golden("g14b_dat_pad_split")
+    cfg = DO.DATConfig(**(DAT_TINY if tag == "s832" else DAT_TINY_816))
+    sd = DO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g[f"{tag}.weight_sha1"]), "DAT weight generator drifted from the one the fixtures were made with"
+    return g, cfg, sd
+
+
+@pytest.mark.parametrize("tag", ["s832", "s816"])
+def test_g14b_dat_padded_frames_and_128_token_windows(tag):
+    """The reference zero-pads q / k / v to a multiple of the larger split (dat_arch.py:376-384): 24x40 and 48x64 inputs with 8x32
+    windows, and the reference's own __main__ split [8, 16] (128-token windows) at padded and unpadded sizes; blocks in isolation on
+    a padded 24x40 frame incl. the shifted one (masks computed for the padded frame, :404-407)."""
+    from oracle import dat_oracle as DO
+    g, cfg, sd = dat_g14b_weights(tag)
+    sizes = ((24, 40), (48, 64), (32, 32)) if tag == "s832" else ((32, 32), (24, 40), (40, 16))
+    for hw in sizes:
+        x = torch.from_numpy(g[f"{tag}.x_{hw[0]}x{hw[1]}"])
+        with torch.no_grad():
+            y = DO.dat_forward(sd, cfg, x)
+        ref = torch.from_numpy(g[f"{tag}.y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape == (1, 3, hw[0] * 2, hw[1] * 2)
+        assert (y - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), (tag, hw)
+    xt = torch.randn(1, 24 * 40, 48, generator=torch.Generator().manual_seed(int(g["blk_seed"])))
+    with torch.no_grad():
+        for name, b in (("blk_shifted_24x40", 2), ("blk_plain_24x40", 0)):
+            ref = torch.from_numpy(g[f"{tag}.{name}"])
+            got = DO.datb(xt, 24, 40, sd, f"layers.0.blocks.{b}.", cfg, 4, 0, b)
+            assert (got - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), (tag, name)

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "srk_stem_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "srk_swin_block_fwd": (_i, [_vp] * 16 + [_f] + [_i] * 8 + [_vp]),
     "srk_win256_attention_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "srk_win_attention_fwd_padded": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "srk_channel_gate_workspace": (_sz, [_i, _i, _i]),
     "srk_channel_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "srk_channel_gate_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -32,8 +32,11 @@ struct Win256Params {
   const float* bias;   // dense: [nH][256][NK];  table: the relative_position_bias_table parameter [table_rows][nH]
   int table_rows;      // > 0: bias comes from the table through the closed-form relative position index (no dense tensor)
   int ldq, ldo, CA;
-  int B, H, W;         // feature map
-  int wh, ww;          // query window (wh * ww == 256)
+  int B, H, W;         // feature map (token addressing)
+  int Hp, Wp;          // window frame: H, W zero-padded at the bottom / right to multiples of the window (DAT: dat_arch.py:376-384
+                       // pads q, k, v to a multiple of the larger split; padded tokens are zero vectors that take part in the softmax
+                       // of their window with score = bias, and their outputs are dropped).  == H, W when nothing is padded
+  int wh, ww;          // query window (wh * ww == 64 * QT)
   int sy, sx;          // cyclic shift (self-attention), 0 = none
   int kh, kw, pad;     // key window: == (wh, ww, 0) for self-attention; (24, 24, 4) for the overlapping cross-attention
   int nWh, nWw, nH;
@@ -46,9 +49,11 @@ __device__ __forceinline__ int region_label(int v, int n, int w, int s) { return
 // through the closed-form index -- rpi_sa[p][k] = (yp - yk + ws - 1)(2 ws - 1) + (xp - xk + ws - 1) (hat_arch.py:881-894),
 // rpi_oca[p][k] = (yk - yp + ws - wse + 1)(ws + wse - 1) + (xk - xp + ws - wse + 1), wrapped by the table length when negative
 // (:896-918 + torch's negative indexing) -- instead of streaming a dense [256][NK] fp32 slab per workgroup from L2.
-template <int NT, bool OCA, bool TABLE>        // NT = key tiles of 16 (16: 256 keys, 36: 576 keys)
+// QT = 16-query tiles per wave: 4 (256-token windows) or 2 (128-token windows: DAT's split_size [8, 16])
+template <int NT, bool OCA, bool TABLE, int QT = 4>        // NT = key tiles of 16 (8: 128 keys, 16: 256 keys, 36: 576 keys)
 __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel(const Win256Params p) {
   constexpr int NK = NT * 16;
+  constexpr int NQ = 64 * QT;                            // queries per window
   constexpr int KW = OCA ? 24 : 16;                      // key-window width in table mode (16 x 16 / 24 x 24 windows)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);          // [NK][KP]
@@ -66,11 +71,12 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel
   // query fragment of a 16-query tile: requested one tile ahead (the first one before the K / V staging), so that its round trip
   // runs under the previous tile's work instead of in front of every tile's dependent chain
   auto load_q = [&](int qt) {
-    const int ql = wave * 64 + qt * 16 + r16;
+    const int ql = wave * (16 * QT) + qt * 16 + r16;
     const int qy = ql / p.ww, qx = ql - qy * p.ww;
     int y = wy * p.wh + qy + p.sy, x = wx * p.ww + qx + p.sx;
-    if (y >= p.H) y -= p.H;
-    if (x >= p.W) x -= p.W;
+    if (y >= p.Hp) y -= p.Hp;
+    if (x >= p.Wp) x -= p.Wp;
+    if (y >= p.H || x >= p.W) return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};          // zero padding of the window frame
     return *reinterpret_cast<const bf16x8_t*>(p.qkv + (tok0 + (long long)y * p.W + x) * p.ldq + h * 32 + 8 * g);
   };
   bf16x8_t qf_next = load_q(0);
@@ -86,8 +92,9 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel
     } else {
       y = wy * p.wh + ky + p.sy;
       x = wx * p.ww + kx + p.sx;
-      if (y >= p.H) y -= p.H;
-      if (x >= p.W) x -= p.W;
+      if (y >= p.Hp) y -= p.Hp;
+      if (x >= p.Wp) x -= p.Wp;
+      ok = y < p.H && x < p.W;
     }
     uint4 kv[4], vv[4];
     if (ok) {
@@ -112,26 +119,27 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel
   }
   __syncthreads();
 
-  const float* bias_h = p.bias + (long long)h * 256 * NK;
+  const float* bias_h = p.bias + (long long)h * NQ * NK;
   const bool masked = !OCA && (p.sy > 0 || p.sx > 0);
   // interior windows of a shifted map have one region label throughout: only the last window row / column is masked
   const bool need_mask = masked && (wy == p.nWh - 1 || wx == p.nWw - 1);
 
   // 16 key tiles: the four query tiles are unrolled -- without a loop the compiler does not hoist the per-tile LDS addresses into
   // registers (236 -> ~150 VGPRs), which lets a third workgroup share the CU; 36 key tiles (overlapping windows) stay rolled
-  constexpr int QT_UNROLL = NT <= 16 ? 4 : 1;
+  constexpr int QT_UNROLL = NT <= 16 ? QT : 1;
 #pragma unroll QT_UNROLL
-  for (int qt = 0; qt < 4; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     // this lane's query: window-local index, raster token, region label
-    const int ql = wave * 64 + qt * 16 + r16;
+    const int ql = wave * (16 * QT) + qt * 16 + r16;
     const int qy = ql / p.ww, qx = ql - qy * p.ww;
     int y = wy * p.wh + qy + p.sy, x = wx * p.ww + qx + p.sx;
-    if (y >= p.H) y -= p.H;
-    if (x >= p.W) x -= p.W;
+    if (y >= p.Hp) y -= p.Hp;
+    if (x >= p.Wp) x -= p.Wp;
+    const bool qreal = y < p.H && x < p.W;                 // a query in the zero padding has no token: its row is not stored
     const long long qtok = tok0 + (long long)y * p.W + x;
-    const int qlab = need_mask ? region_label(wy * p.wh + qy, p.H, p.wh, p.sy) * 3 + region_label(wx * p.ww + qx, p.W, p.ww, p.sx) : 0;
+    const int qlab = need_mask ? region_label(wy * p.wh + qy, p.Hp, p.wh, p.sy) * 3 + region_label(wx * p.ww + qx, p.Wp, p.ww, p.sx) : 0;
     const bf16x8_t qf = qf_next;
-    if (qt < 3) qf_next = load_q(qt + 1);
+    if (qt < QT - 1) qf_next = load_q(qt + 1);
 
     // ---- S^T tiles -----------------------------------------------------------------------------------
     f32x4_t s[NT];
@@ -173,12 +181,12 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel
       if (need_mask) {                                                  // border windows only; any window shape with ww % 4 == 0
         const int cm = 16 * j + 4 * g;
         const int kym = cm / p.ww, kxm = cm - kym * p.ww;
-        const int lh = region_label(wy * p.wh + kym, p.H, p.wh, p.sy) * 3;
+        const int lh = region_label(wy * p.wh + kym, p.Hp, p.wh, p.sy) * 3;
         const int xb = wx * p.ww + kxm;
-        if (lh + region_label(xb, p.W, p.ww, p.sx) != qlab) v0 += -100.0f;          // hat_arch.py:939 (-100, not -inf)
-        if (lh + region_label(xb + 1, p.W, p.ww, p.sx) != qlab) v1 += -100.0f;
-        if (lh + region_label(xb + 2, p.W, p.ww, p.sx) != qlab) v2 += -100.0f;
-        if (lh + region_label(xb + 3, p.W, p.ww, p.sx) != qlab) v3 += -100.0f;
+        if (lh + region_label(xb, p.Wp, p.ww, p.sx) != qlab) v0 += -100.0f;          // hat_arch.py:939 (-100, not -inf)
+        if (lh + region_label(xb + 1, p.Wp, p.ww, p.sx) != qlab) v1 += -100.0f;
+        if (lh + region_label(xb + 2, p.Wp, p.ww, p.sx) != qlab) v2 += -100.0f;
+        if (lh + region_label(xb + 3, p.Wp, p.ww, p.sx) != qlab) v3 += -100.0f;
       }
       s[j] = f32x4_t{v0, v1, v2, v3};
       mx = fmaxf(mx, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
@@ -214,19 +222,21 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel
       }
     }
     // lane holds O[q = r16][d = 16 dt + 4 g + 0..3]
+    if (qreal) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-      *reinterpret_cast<uint2*>(p.out + qtok * p.ldo + h * 32 + 16 * dt + 4 * g) =
-          pack_bf4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      for (int dt = 0; dt < 2; ++dt)
+        *reinterpret_cast<uint2*>(p.out + qtok * p.ldo + h * 32 + 16 * dt + 4 * g) =
+            pack_bf4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
   }
 }
 
-template <int NT, bool OCA, bool TABLE>
+template <int NT, bool OCA, bool TABLE, int QT = 4>
 int launch(const Win256Params& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * NT * 16 * KP * sizeof(bf16_t) + (TABLE ? 1536 * sizeof(float) : 0);
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_fwd_kernel<NT, OCA, TABLE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_fwd_kernel<NT, OCA, TABLE, QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       srk_set_error("win256 attention: cannot reserve %zu bytes of LDS", lds);
       return SRK_E_LAUNCH;
@@ -235,7 +245,7 @@ int launch(const Win256Params& p, hipStream_t stream) {
   }
   const long long grid = (long long)p.B * p.nWh * p.nWw * p.nH;
   SRK_REQUIRE(grid > 0 && grid < (1LL << 31), SRK_E_SHAPE, "win256 attention: bad grid %lld", grid);
-  hipLaunchKernelGGL((win256_attn_fwd_kernel<NT, OCA, TABLE>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((win256_attn_fwd_kernel<NT, OCA, TABLE, QT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
   return srk_check_launch("win256_attn_fwd");
 }
 
@@ -243,10 +253,21 @@ int launch(const Win256Params& p, hipStream_t stream) {
 
 int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W,
                                int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream) {
+  return srk_launch_win_attn_fwd_padded(qkv, ldq, CA, bias, table_rows, out, ldo, B, H, W, H, W, wh, ww, sy, sx, nH, scale, overlap, stream);
+}
+
+// Hp x Wp: the window frame -- the H x W map zero-padded at the bottom / right (Hp >= H, Wp >= W, multiples of the window)
+int srk_launch_win_attn_fwd_padded(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H,
+                                   int W, int Hp, int Wp, int wh, int ww, int sy, int sx, int nH, float scale, int overlap,
+                                   hipStream_t stream) {
   SRK_REQUIRE(qkv && bias && out, SRK_E_NULL, "win256 attention: null pointer");
   SRK_REQUIRE(ww % 4 == 0, SRK_E_UNSUPPORTED, "win256 attention: window width %d must be a multiple of 4", ww);
-  SRK_REQUIRE(wh > 0 && ww > 0 && wh * ww == 256, SRK_E_UNSUPPORTED, "win256 attention: the window must hold 256 tokens (got %dx%d)", wh, ww);
-  SRK_REQUIRE(B > 0 && H % wh == 0 && W % ww == 0, SRK_E_SHAPE, "win256 attention: %dx%d is not a multiple of the %dx%d window", H, W, wh, ww);
+  SRK_REQUIRE(wh > 0 && ww > 0 && (wh * ww == 256 || wh * ww == 128), SRK_E_UNSUPPORTED,
+              "win256 attention: the window must hold 256 or 128 tokens (got %dx%d)", wh, ww);
+  SRK_REQUIRE(B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && Hp % wh == 0 && Wp % ww == 0, SRK_E_SHAPE,
+              "win256 attention: window frame %dx%d must cover the %dx%d map and be a multiple of the %dx%d window", Hp, Wp, H, W, wh, ww);
+  SRK_REQUIRE(overlap == 0 || (Hp == H && Wp == W && wh * ww == 256), SRK_E_UNSUPPORTED,
+              "overlapping cross-attention takes unpadded maps and 16x16 windows");
   // CA is the column distance between the q, k and v blocks of a row; a caller may run a SUBSET of the heads (DAT's two branches take
   // heads 0..nH/2-1 and nH/2..nH-1 with different window shapes) by offsetting qkv / out by 32 * first_head
   SRK_REQUIRE(nH > 0 && CA >= nH * 32 && CA % 32 == 0 && ldq >= 3 * CA && ldq % 8 == 0 && ldo >= nH * 32 && ldo % 4 == 0, SRK_E_SHAPE,
@@ -259,14 +280,19 @@ int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* 
                 "win256 attention: table-indexed bias is built for 16x16 windows (961 rows; 1521 for the overlapping form), got %d rows",
                 table_rows);
   }
-  p.qkv = qkv; p.out = out; p.bias = bias; p.ldq = ldq; p.ldo = ldo; p.CA = CA; p.B = B; p.H = H; p.W = W; p.wh = wh; p.ww = ww;
-  p.sy = sy; p.sx = sx; p.kh = wh; p.kw = ww; p.pad = 0; p.nWh = H / wh; p.nWw = W / ww; p.nH = nH; p.scale = scale;
+  p.qkv = qkv; p.out = out; p.bias = bias; p.ldq = ldq; p.ldo = ldo; p.CA = CA; p.B = B; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp;
+  p.wh = wh; p.ww = ww;
+  p.sy = sy; p.sx = sx; p.kh = wh; p.kw = ww; p.pad = 0; p.nWh = Hp / wh; p.nWw = Wp / ww; p.nH = nH; p.scale = scale;
   if (overlap > 0) {
     // overlapping cross-attention: key window = window + 2 * overlap per side-pair, i.e. wh + overlap: overlap = int(ratio * ws)
     SRK_REQUIRE(wh == 16 && ww == 16 && overlap == 8 && sy == 0 && sx == 0, SRK_E_UNSUPPORTED,
                 "overlapping cross-attention is built for 16x16 windows with overlap 8 (24x24 keys), no shift");
     p.kh = wh + overlap; p.kw = ww + overlap; p.pad = overlap / 2;
     return table_rows > 0 ? launch<36, true, true>(p, stream) : launch<36, true, false>(p, stream);
+  }
+  if (wh * ww == 128) {
+    SRK_REQUIRE(table_rows == 0, SRK_E_UNSUPPORTED, "win256 attention: 128-token windows take a dense bias");
+    return launch<8, false, false, 2>(p, stream);
   }
   return table_rows > 0 ? launch<16, false, true>(p, stream) : launch<16, false, false>(p, stream);
 }

@@ -184,6 +184,13 @@ int srk_win256_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* 
                                     (hipStream_t)stream);
 }
 
+int srk_win_attention_fwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, int table_rows, uint16_t* out, int ldo, int B, int H,
+                                 int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x, int num_heads, float scale, int overlap,
+                                 srk_stream_t stream) {
+  return srk_launch_win_attn_fwd_padded(qkv, ldq, CA, bias, table_rows, out, ldo, B, H, W, Hp, Wp, wh, ww, shift_y, shift_x, num_heads, scale,
+                                        overlap, (hipStream_t)stream);
+}
+
 int srk_swin_block_fwd(const float* x, float* y, uint16_t* y_bf16, const float* norm1_w, const float* norm1_b, const float* norm2_w,
                        const float* norm2_b, const uint16_t* wqkv, const float* bqkv, const uint16_t* wproj, const float* bproj,
                        const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* bias_dense, float scale,

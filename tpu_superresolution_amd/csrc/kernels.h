@@ -68,3 +68,4 @@ int srk_launch_sumsq(const float* g, long long n, float* out, hipStream_t stream
 int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, const float* sumsq, const int* nonfinite, float max_norm, float grad_div, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t stream);
 int srk_launch_probe_trread(const bf16_t* in, bf16_t* out, hipStream_t stream);
 int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W, int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream);
+int srk_launch_win_attn_fwd_padded(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W, int Hp, int Wp, int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream);

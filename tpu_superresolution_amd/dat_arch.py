@@ -252,8 +252,8 @@ class DAT(nn.Module):
     def _unsupported_reason(self) -> Optional[str]:
         C_ = self.embed_dim
         s0, s1 = self.split_size
-        if s0 * s1 != 256 or s0 % 4 or s1 % 4:
-            return f"split_size={self.split_size} (the attention kernel holds 256 tokens per window, sides multiples of 4)"
+        if s0 * s1 not in (128, 256) or s0 % 4 or s1 % 4:
+            return f"split_size={self.split_size} (the attention kernel holds 256 or 128 tokens per window, sides multiples of 4)"
         if self.resi_connection != '1conv':
             return f"resi_connection={self.resi_connection!r}"
         if self.upsampler not in ('pixelshuffle', 'pixelshuffledirect'):
@@ -393,8 +393,7 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
     B, Cin, H, W = x.shape
     s0, s1 = m.split_size
     big = max(s0, s1)
-    if H % big or W % big:
-        raise SrkUnsupported(f"DAT on the HIP path needs H, W multiples of {big} (got {H}x{W}); the reference zero-pads q/k/v otherwise")
+    Hp, Wp = _rup(H, big), _rup(W, big)        # window frame: q / k / v zero-padded to a multiple of the larger split (:376-384)
     T, HW, s = B * H * W, H * W, m.upscale
     C_, CP = m.embed_dim, _rup(m.embed_dim, 64)
     half = int(C_ * m.expansion_factor) // 2
@@ -446,8 +445,8 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
                 for br, (hs, wsz) in enumerate(((s0, s1), (s1, s0))):       # two window orientations on the two halves of the heads
                     sy, sx = (hs // 2, wsz // 2) if at.shifted else (0, 0)
                     off = br * hb * 32 * 2
-                    check(L.srk_win256_attention_fwd(qkv.data_ptr() + off, 3 * CA, CA, P[pre + f"bias{br}"].data_ptr(), 0, att.data_ptr() + off, CA,
-                                                     B, H, W, hs, wsz, sy, sx, hb, scale, 0, st))
+                    check(L.srk_win_attention_fwd_padded(qkv.data_ptr() + off, 3 * CA, CA, P[pre + f"bias{br}"].data_ptr(), 0,
+                                                         att.data_ptr() + off, CA, B, H, W, Hp, Wp, hs, wsz, sy, sx, hb, scale, 0, st))
                 gate_src, tok_src, tok_on_a = conv, att, 0            # channel map from the conv branch, spatial map from the attention
             else:
                 check(L.srk_channel_attention_fwd(qkv.data_ptr(), 3 * CA, CA, P[pre + "temp"].data_ptr(), ca_ws.data_ptr(), att.data_ptr(), CA, B, HW,
