@@ -374,6 +374,9 @@ typedef struct {
   float mean[3];         /* (0.4488, 0.4371, 0.4040) for 3-channel input, 0 otherwise (:658-662) */
   float qk_scale;        /* <= 0: head_dim ** -0.5 */
   int resi_connection;   /* SRK_RESI_* */
+  int ape;               /* constructor ape: != 0 -> parameter absolute_pos_embed [1][img_size^2][C] (first in the parameter table, as in
+                            named_parameters()), added to the tokens after patch_embed.norm (network_swinir.py:678-689, :793-795); the
+                            input must then have exactly img_size x img_size tokens, as in the reference */
   int use_checkpoint;    /* constructor use_checkpoint (network_swinir.py:397-405 wraps every block in torch.utils.checkpoint): != 0 ->
                             a training forward keeps, per block, only what cannot be recomputed cheaply (norm1 / norm2 outputs, the
                             residual rows, statistics); the attention output and the MLP's u / h = gelu(u) live in ONE shared set of

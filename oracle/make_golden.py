@@ -183,6 +183,37 @@ DAT_TINY_816 = dict(img_size=32, in_chans=3, embed_dim=48, split_size=(8, 16), d
                     upscale=2, img_range=1.0, resi_connection="1conv", upsampler="pixelshuffle")
 
 
+TINY_APE = dict(img_size=16, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8, mlp_ratio=2, img_range=1.0,
+                resi_connection="1conv", upscale=2, upsampler="pixelshuffle", ape=True)
+
+
+def gen_g15():
+    """G15: SwinIR with ape=True (absolute_pos_embed added after patch_embed, network_swinir.py:678-689, :793-795).  The embedding has
+    img_size^2 rows, so the reference only runs at exactly img_size x img_size: forward there, and one training record (loss +
+    every gradient, incl. the embedding's)."""
+    ns = import_reference("network_swinir")
+    cfg = O.SwinIRConfig(**TINY_APE)
+    sd = O.random_state_dict(cfg, seed=16, scale=3.0)
+    m = build_ref_model(ns, cfg, sd)
+    assert list(m.state_dict().keys()) == [k for k, _, _ in O.state_dict_schema(cfg)]
+    arrays = {"weight_seed": np.array(16), "weight_scale": np.array(3.0),
+              "weight_sha1": np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()])))}
+    gi = torch.Generator().manual_seed(160)
+    xin = torch.rand(2, 3, 16, 16, generator=gi)
+    with torch.no_grad():
+        arrays["x_16x16"], arrays["y_16x16"] = xin.numpy(), m(xin).numpy()
+    mt = build_ref_model(ns, cfg, sd).train()
+    xt = torch.rand(2, 3, 16, 16, generator=gi)
+    tgt = torch.rand(2, 3, 32, 32, generator=gi)
+    loss = torch.nn.functional.l1_loss(mt(xt), tgt)
+    loss.backward()
+    arrays["train.x"], arrays["train.target"], arrays["train.loss"] = xt.numpy(), tgt.numpy(), loss.detach().numpy()
+    for n_, p in mt.named_parameters():
+        arrays["grad." + n_] = p.grad.detach().numpy().copy()
+    arrays["param_order"] = np.array([n_ for n_, _ in mt.named_parameters()])
+    save("g15_tiny_ape", **arrays)
+
+
 def gen_g14b():
     """G14b: DAT with the reference's zero padding of q / k / v (input sizes that are not multiples of the larger split:
     dat_arch.py:376-384 + the on-the-fly masks of :404-407) and with 128-token windows -- split_size [8, 16], expansion_factor 2,
@@ -289,10 +320,13 @@ def main():
         return gen_g13()
     if "--only-g14b" in sys.argv:
         return gen_g14b()
+    if "--only-g15" in sys.argv:
+        return gen_g15()
     gen_g11()
     gen_g13()
     gen_g14()
     gen_g14b()
+    gen_g15()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------

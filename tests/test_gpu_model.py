@@ -195,7 +195,7 @@ def test_errors_are_loud():
         m(torch.rand(1, 3, 16, 16))
     with pytest.raises(ValueError, match="scale 5 is not supported"):
         T.SwinIR(**{**cfg.kwargs(), "upscale": 5})
-    for bad in (dict(window_size=7, img_size=14), dict(ape=True), dict(patch_norm=False)):
+    for bad in (dict(window_size=7, img_size=14), dict(patch_norm=False)):
         mm = T.SwinIR(**{**cfg.kwargs(), **bad}).cuda()
         with pytest.raises(NotImplementedError):
             mm(torch.rand(1, 3, 16, 16, device="cuda"))
@@ -365,3 +365,52 @@ def test_light_whole_block_kernel_matches_layer_per_launch_path():
         ref = O.swinir_forward(sd, cfg, x)
         got = build(cfg, sd)(x.cuda()).float().cpu()
     assert float((got - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+
+
+def test_upsample_one_step_backward_at_embed_180_vs_oracle():
+    """UpsampleOneStep (network_swinir.py:594-615, 'pixelshuffledirect') at the classical width: its conv has 12 output channels from
+    180 inputs -- the small-Cout dgrad stages 83 KB of weights in LDS (it used to refuse anything above the 64 KB default).  Forward,
+    loss and gradients against the CPU oracle (pinned for this head by the psd2 goldens)."""
+    cfg = O.SwinIRConfig(upscale=2, in_chans=3, img_size=16, window_size=8, img_range=1.0, depths=(2,), embed_dim=180, num_heads=(6,),
+                         mlp_ratio=2.0, upsampler="pixelshuffledirect", resi_connection="1conv")
+    sd = O.random_state_dict(cfg, seed=9, scale=1.5)
+    x, t = O.synthetic_batch(2, 16, 2, seed=10)
+    m = build(cfg, sd, train=True)
+    loss = torch.nn.functional.l1_loss(m(x.cuda()), t.cuda())
+    loss.backward()
+    ref_loss, _, grads = O.loss_and_grads(sd, cfg, x, t)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * float(ref_loss)
+    rels = {n: float((p.grad.cpu() - grads[n]).norm() / (grads[n].norm() + 1e-12)) for n, p in m.named_parameters()}
+    worst = max(rels, key=rels.get)
+    assert rels[worst] <= 0.15, (worst, rels[worst])
+    assert float(np.median(list(rels.values()))) <= 0.04
+
+
+def test_ape_forward_and_gradients_vs_reference_golden():
+    """ape=True (network_swinir.py:678-689, :793-795): G15 from the imported reference -- forward at img_size x img_size, loss and every
+    gradient incl. absolute_pos_embed's; any other input size fails as it does in the reference (the embedding has img_size^2 rows)."""
+    import tpu_superresolution_amd as T
+    from conftest import load_golden
+    from test_oracle_golden import TINY_APE
+    g = load_golden("g15_tiny_ape")
+    cfg = O.SwinIRConfig(**TINY_APE)
+    sd = O.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    m = build(cfg, sd)
+    assert [n for n, _ in m.named_parameters()] == [str(s_) for s_ in g["param_order"]]
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x_16x16"]).cuda()).cpu()
+    ref = torch.from_numpy(g["y_16x16"])
+    assert float((y - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+    m = build(cfg, sd, train=True)
+    loss = torch.nn.functional.l1_loss(m(torch.from_numpy(g["train.x"]).cuda()), torch.from_numpy(g["train.target"]).cuda())
+    loss.backward()
+    assert abs(float(loss) - float(g["train.loss"])) <= 2e-3 * float(g["train.loss"])
+    rels = {}
+    for n, p_ in m.named_parameters():
+        r = torch.from_numpy(g["grad." + n])
+        rels[n] = float((p_.grad.cpu() - r).norm() / (r.norm() + 1e-12))
+    assert max(rels.values()) <= 0.1, max(rels, key=rels.get)
+    assert float(np.median(list(rels.values()))) <= 0.04        # (absolute_pos_embed itself: 0.06, inside the per-tensor bound above)
+    from tpu_superresolution_amd._lib import SrkError
+    with pytest.raises((SrkError, ValueError, RuntimeError), match="must match the size"):
+        build(cfg, sd)(torch.rand(1, 3, 24, 24, device="cuda"))

@@ -385,3 +385,26 @@ def test_g14b_dat_padded_frames_and_128_token_windows(tag):
             ref = torch.from_numpy(g[f"{tag}.{name}"])
             got = DO.datb(xt, 24, 40, sd, f"layers.0.blocks.{b}.", cfg, 4, 0, b)
             assert (got - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), (tag, name)
+
+
+# ---- G15: SwinIR with ape=True ------------------------------------------------------------------------------------------------------
+TINY_APE = dict(img_size=16, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8, mlp_ratio=2, img_range=1.0,
+                resi_connection="1conv", upscale=2, upsampler="pixelshuffle", ape=True)
+
+
+def test_g15_ape_forward_and_gradients():
+    g = load_golden("g15_tiny_ape")
+    cfg = O.SwinIRConfig(**TINY_APE)
+    sd = O.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g["weight_sha1"])
+    with torch.no_grad():
+        y = O.swinir_forward(sd, cfg, torch.from_numpy(g["x_16x16"]))
+    ref = torch.from_numpy(g["y_16x16"])
+    assert (y - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+    loss, _, grads = O.loss_and_grads(sd, cfg, torch.from_numpy(g["train.x"]), torch.from_numpy(g["train.target"]))
+    assert abs(float(loss) - float(g["train.loss"])) < 1e-5
+    for n, gr in grads.items():
+        r = torch.from_numpy(g["grad." + n])
+        assert (gr - r).abs().max() < 1e-5 * max(1.0, float(r.abs().max())), n
+    assert "absolute_pos_embed" in grads

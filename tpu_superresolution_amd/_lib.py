@@ -32,7 +32,7 @@ class SwinIRConfig(C.Structure):
     _fields_ = [("img_size", C.c_int), ("in_chans", C.c_int), ("embed_dim", C.c_int), ("num_layers", C.c_int),
                 ("depths", C.c_int * 16), ("num_heads", C.c_int * 16), ("window_size", C.c_int),
                 ("hidden_dim", C.c_int), ("upscale", C.c_int), ("upsampler", C.c_int), ("img_range", C.c_float),
-                ("mean", C.c_float * 3), ("qk_scale", C.c_float), ("resi_connection", C.c_int), ("use_checkpoint", C.c_int)]
+                ("mean", C.c_float * 3), ("qk_scale", C.c_float), ("resi_connection", C.c_int), ("ape", C.c_int), ("use_checkpoint", C.c_int)]
 
 
 class GemmArgs(C.Structure):

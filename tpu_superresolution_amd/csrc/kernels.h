@@ -59,6 +59,8 @@ int srk_launch_batch_psnr(const float* pred, const float* target, float* partial
 int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream);
 int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStream_t stream);
 int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream);
+int srk_launch_ape_add(float* x, const float* ape, int B, int L, int C, int CP, hipStream_t stream);
+int srk_launch_ape_grad(const float* gx, float* dape, int B, int L, int C, int CP, hipStream_t stream);
 int srk_launch_dlrelu_bf16(bf16_t* g, const bf16_t* act, float slope, long long n, hipStream_t stream);
 int srk_launch_nn2x_bf16(const bf16_t* in, bf16_t* out, int B, int h, int w, int C, hipStream_t stream);
 int srk_launch_nn2x_sum_dlrelu(const bf16_t* g, const bf16_t* act, bf16_t* out, int B, int h, int w, int C, float slope, hipStream_t stream);

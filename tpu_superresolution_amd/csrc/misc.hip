@@ -619,6 +619,25 @@ __global__ void add_bf16_into_f32_kernel(float* __restrict__ a, const bf16_t* __
   }
 }
 
+// absolute position embedding (network_swinir.py:793-795): x[b][l][c] += ape[l][c]; x rows are CP wide, ape rows C wide
+__global__ void ape_add_kernel(float* __restrict__ x, const float* __restrict__ ape, long long rows, int L, int C, int CP) {
+  const long long n = rows * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = i / C;
+    const int c = (int)(i - t * C);
+    x[t * CP + c] += ape[(t % L) * C + c];
+  }
+}
+// its gradient: d ape[l][c] += sum_b gx[b][l][c]  (one thread per (l, c), batch summed in order)
+__global__ void ape_grad_kernel(const float* __restrict__ gx, float* __restrict__ dape, int B, int L, int C, int CP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * C) return;
+  const int l = i / C, c = i - l * C;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += gx[((long long)b * L + l) * CP + c];
+  dape[i] += a;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ a, bf16_t* __restrict__ out, long long n4) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const float4 x = reinterpret_cast<const float4*>(a)[i];
@@ -1020,7 +1039,20 @@ int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, in
     if (rc != SRK_WGRAD_NOT_COVERED) return rc;
   }
   const size_t lds = (size_t)(9 * Co * CinP + 16 * 9 * CoP) * sizeof(float);
-  SRK_REQUIRE(lds <= 64 * 1024, SRK_E_SHAPE, "smallconv dgrad: LDS %zu too large", lds);
+  // UpsampleOneStep at embed_dim 180 (network_swinir.py:594-615: 12 or 16 output channels from 192 padded inputs) stages up to
+  // 120 KB of weights: more than the default 64 KB dynamic-LDS limit, well inside the CU's 160 KB
+  SRK_REQUIRE(lds <= 160 * 1024, SRK_E_SHAPE, "smallconv dgrad: LDS %zu too large", lds);
+  if (lds > 64 * 1024) {
+    static size_t reserved = 0;
+    if (lds > reserved) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess) {
+        srk_set_error("smallconv dgrad: cannot reserve %zu bytes of LDS", lds);
+        return SRK_E_LAUNCH;
+      }
+      reserved = 160 * 1024;
+    }
+  }
   const long long npix = (long long)B * H * W;
   const int groups = npix >= (1 << 20) ? 32 : 4;
   hipLaunchKernelGGL(smallconv_dgrad_kernel, dim3((unsigned)((npix + 16 * groups - 1) / (16 * groups))), dim3(256), lds, stream,
@@ -1070,6 +1102,16 @@ int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStre
   SRK_REQUIRE(n % 4 == 0, SRK_E_SHAPE, "add: n %% 4 != 0");
   hipLaunchKernelGGL(add_bf16_into_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a, b, n / 4);
   return srk_check_launch("add_bf16");
+}
+
+int srk_launch_ape_add(float* x, const float* ape, int B, int L, int C, int CP, hipStream_t stream) {
+  hipLaunchKernelGGL(ape_add_kernel, dim3(grid_for((long long)B * L * C)), dim3(256), 0, stream, x, ape, (long long)B * L, L, C, CP);
+  return srk_check_launch("ape_add");
+}
+
+int srk_launch_ape_grad(const float* gx, float* dape, int B, int L, int C, int CP, hipStream_t stream) {
+  hipLaunchKernelGGL(ape_grad_kernel, dim3((L * C + 255) / 256), dim3(256), 0, stream, gx, dape, B, L, C, CP);
+  return srk_check_launch("ape_grad");
 }
 
 int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream) {

@@ -93,6 +93,7 @@ struct srk_swinir_plan {
   ConvW conv_before_up, conv_last, up_direct, conv_hr;
   std::vector<ConvW> up_convs;       // 'pixelshuffle': conv + PixelShuffle stages; 'nearest+conv': conv_up1, conv_up2
   long long p_conv_first_w, p_conv_first_b, p_pe_w, p_pe_b, p_norm_w, p_norm_b;
+  long long p_ape = -1;        // absolute_pos_embed [1][img_size^2][C] (cfg.ape) or -1
   // pack descriptors, grouped: group 0 = head, 1..L = layers, L+1 = tail
   std::vector<PackDesc> descs;
   std::vector<int> group_desc_begin, group_blocks;   // size L+3 / L+2
@@ -501,6 +502,7 @@ int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** out) 
   p->group_desc_begin.push_back(0);
   p->group_param_begin.push_back(0);
   // ---- group 0: head ----
+  if (cfg->ape) p->p_ape = add_param(p, "absolute_pos_embed", {1, (long long)cfg->img_size * cfg->img_size, C});   // a direct parameter: first
   p->p_conv_first_w = add_param(p, "conv_first.weight", {C, cfg->in_chans, 3, 3});
   p->p_conv_first_b = add_param(p, "conv_first.bias", {C});
   p->p_pe_w = add_param(p, "patch_embed.norm.weight", {C});
@@ -722,6 +724,12 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
 
   RUN(srk_launch_ln_fwd(c.at<float>(w.f0), params + p->p_pe_w, params + p->p_pe_b, nullptr, c.at<float>(w.x0),
                         c.at<float>(w.mean_pe), c.at<float>(w.rstd_pe), T, C, CP, nullptr, st));
+  if (p->p_ape >= 0) {       // x = x + absolute_pos_embed  (:793-795)
+    const int L_ = p->cfg.img_size * p->cfg.img_size;
+    SRK_REQUIRE(HW == L_, SRK_E_SHAPE, "The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1 "
+                "(ape=True: absolute_pos_embed has img_size^2 rows)", HW, L_);
+    RUN(srk_launch_ape_add(c.at<float>(w.x0), params + p->p_ape, B, L_, C, CP, st));
+  }
 
   for (int l = 0; l < p->L; ++l) {
     const int first = p->layer_first_blk[l], depth = p->cfg.depths[l];
@@ -1284,6 +1292,8 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
       RUN(unpack_group(c, l + 1, grads));
     } else {
       // ---------------- head: patch_embed.norm, long skip, conv_first ----------------
+      if (p->p_ape >= 0)      // d absolute_pos_embed = batch sum of the gradient of the first layer's input
+        RUN(srk_launch_ape_grad(c.at<float>(w.gx), grads + p->p_ape, B, p->cfg.img_size * p->cfg.img_size, C, CP, st));
       RUN(srk_launch_ln_bwd(c.at<bf16_t>(w.gxb), c.at<float>(w.f0), c.at<float>(w.mean_pe), c.at<float>(w.rstd_pe),
                             params + p->p_pe_w, c.at<float>(w.gx2), nullptr, grads + p->p_pe_w, grads + p->p_pe_b, T, C, CP, nullptr, 0,
                             0, 0, 0, nullptr, HW, st));

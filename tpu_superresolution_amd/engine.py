@@ -30,7 +30,8 @@ class SwinIRPlan:
 
     def __init__(self, *, img_size: int, in_chans: int, embed_dim: int, depths: Sequence[int], num_heads: Sequence[int],
                  window_size: int, mlp_ratio: float, upscale: int, img_range: float, upsampler: str,
-                 qk_scale: Optional[float] = None, resi_connection: str = "1conv", use_checkpoint: bool = False):
+                 qk_scale: Optional[float] = None, resi_connection: str = "1conv", use_checkpoint: bool = False,
+                 ape: bool = False):
         # any other upsampler string takes the reference's `else` branch: the denoising head (network_swinir.py:760-762)
         ups = _lib.UPSAMPLERS.get(upsampler, _lib.UPSAMPLER_NONE)
         if resi_connection not in _lib.RESI:
@@ -56,6 +57,7 @@ class SwinIRPlan:
         cfg.qk_scale = float(qk_scale) if qk_scale else 0.0
         cfg.resi_connection = _lib.RESI[resi_connection]
         cfg.use_checkpoint = 1 if use_checkpoint else 0
+        cfg.ape = 1 if ape else 0
         self.cfg = cfg
         self.upscale = int(upscale)
         self.n_blocks = int(sum(depths))

@@ -317,8 +317,6 @@ class SwinIR(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _unsupported_reason(self) -> Optional[str]:
-        if self.ape:
-            return "ape=True"
         if not self.patch_norm:
             return "patch_norm=False"
         if not self.qkv_bias:
@@ -340,7 +338,7 @@ class SwinIR(nn.Module):
                                     depths=self.depths, num_heads=self.heads, window_size=self.window_size,
                                     mlp_ratio=self.mlp_ratio, upscale=self.upscale, img_range=self.img_range,
                                     upsampler=self.upsampler, qk_scale=self.qk_scale, resi_connection=self.resi_connection,
-                                    use_checkpoint=self.use_checkpoint)
+                                    use_checkpoint=self.use_checkpoint, ape=bool(self.ape))
         eng = SwinIREngine(self._plan, device)
         named = dict(self.named_parameters())
         missing = [p.name for p in self._plan.params if p.name not in named]
