@@ -352,6 +352,62 @@ size_t srk_channel_attention_workspace(int B, int N, int num_heads);
 int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* temperature, void* workspace, uint16_t* out, int ldo, int B,
                               int N, int num_heads, int head_dim, srk_stream_t stream);
 
+/* ---- DAT training pieces (csrc/dat_train.hip, csrc/attn_rect_bwd.hip) -----------------------------------------------------------
+ * Token-sized work and token reductions only: the per-channel / per-sample functions in between (train-mode BatchNorm coefficients
+ * dat_arch.py:301-313 / :464-476, channel_interaction on the pooled [B][C] vector, the d x d channel-attention matrices :497-503,
+ * the DynamicPosBias MLP :93-130) are evaluated by the caller on the reductions these return (tpu_superresolution_amd/dat_train.py).
+ * All bf16 operands are row-major [rows][ld] with 8-element (16-byte) aligned rows; C8 = channels / 8. */
+/* backward of srk_win_attention_fwd_padded with a dense bias: d_qkv (q | k | v slices of the heads of this launch) and d_bias
+ * [heads][N][N] ACCUMULATED (zero it first) over the windows */
+int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, const uint16_t* d_out, int ldo, uint16_t* d_qkv,
+                                 float* d_bias, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x, int num_heads,
+                                 float scale, srk_stream_t stream);
+/* partial [samples][chunks][2][8 C8]: per 256-row chunk of a sample, sum_t p[t][c] and sum_t p[t][c] q[t][c] (fixed order; the caller
+ * sums the chunks).  BatchNorm batch statistics (q = p), its backward sums (p = dz, q = x), the pooled mean (samples = B). */
+int64_t srk_chan_stats_chunks(int64_t rows_per_sample);
+int srk_chan_stats(const uint16_t* p, int ldp, const uint16_t* q, int ldq, float* partial, int samples, int64_t rows_per_sample, int C8,
+                   srk_stream_t stream);
+/* out = act(x * scale[i][c] + shift[i][c]); i = row / rows_per_sample (rows_per_sample 0: one vector for all rows); act 1 = GELU */
+int srk_affine_act_bf16(const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out, int ldo, int64_t rows, int C8,
+                        int rows_per_sample, int act, srk_stream_t stream);
+/* out = dy * gelu'(x * scale[c] + shift[c]) */
+int srk_dgelu_affine_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out,
+                          int ldo, int64_t rows, int C8, srk_stream_t stream);
+/* out (+)= A[i][c] p + B[i][c] q + C[i][c]   (null A / B: coefficient 1; null p / q: no such term; accumulate: out is read first) */
+int srk_lincomb2_bf16(const uint16_t* p, int ldp, const uint16_t* q, int ldq, const float* A, const float* Bc, const float* Cc, uint16_t* out,
+                      int ldo, int64_t rows, int C8, int rows_per_sample, int accumulate, srk_stream_t stream);
+/* d a = dy * b, d b = dy * a  (SpatialGate's x1 * x2, dat_arch.py:54) */
+int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* da, int ldda, uint16_t* db,
+                     int lddb, int64_t rows, int C8, srk_stream_t stream);
+/* depth-wise 3x3 (pad 1): partial [B][ceil(H / 8)][10][8 C8]; rows 0..8 the taps' weight gradient, row 9 the bias gradient */
+int srk_dwconv3x3_wgrad(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, float* partial, int B, int H, int W, int C8,
+                        srk_stream_t stream);
+/* backward of srk_dual_gate_combine, out = a_chan * cgate[b][c] + a_tok * tgate[t]:  d_chan = d * cgate, d_tok = d * tgate,
+ * dcg_partial [B][ceil(HW / 64)][CA] = chunk sums of d * a_chan  (gradient w.r.t. the post-sigmoid channel gate),
+ * dsmap [B * HW] = (sum_c d * a_tok) * tgate (1 - tgate)   (gradient w.r.t. the PRE-sigmoid spatial map) */
+int srk_dual_gate_bwd(const uint16_t* dcomb, const uint16_t* a_chan, const uint16_t* a_tok, const float* cgate, const float* tgate,
+                      uint16_t* d_chan, uint16_t* d_tok, float* dcg_partial, float* dsmap, int B, int HW, int CA, srk_stream_t stream);
+/* spatial_interaction in training (:318-323 / :475-480): y1 = W0 x + b0 (S <= 16), z = y1 * bn_scale + bn_shift, smap = w3 . gelu(z) + b3.
+ *   what 0: partial [blocks][2][16]  = sums of y1, y1^2 over each 256-row block (BatchNorm batch statistics)
+ *   what 1: partial [blocks][4][16]  = sums of dz, dz * y1, dsmap * gelu(z), dsmap (in slot 0) with dz = dsmap * w3 * gelu'(z)
+ *   what 2: dy1 = cA * dz + cB * y1 + cC (the BatchNorm backward, coefficients from the caller); dx (+)= W0^T dy1;
+ *           partial [blocks][16][C + 1] = the block's d W0 [s][c] (first 16 C floats) and d b0 [s] (last 16) */
+int srk_spatial_gate_train(int what, const uint16_t* x, int ldx, const float* W0, const float* b0, const float* bn_scale, const float* bn_shift,
+                           const float* w3, const float* dsmap, const float* cA, const float* cB, const float* cC, uint16_t* dx, int lddx,
+                           int accumulate, float* partial, int64_t rows, int C, int S, srk_stream_t stream);
+/* LayerNorm (eps 1e-5) backward on bf16 rows (SpatialGate.norm): dx bf16 (columns C..CP_out zero); partial [blocks][2][C] with the
+ * workgroups' d gamma / d beta sums, blocks = srk_rowln_bwd_blocks(rows) */
+int64_t srk_rowln_bwd_blocks(int64_t rows);
+int srk_rowln_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* gamma, uint16_t* dx, int lddx, float* partial,
+                       int64_t rows, int C, int CP_out, srk_stream_t stream);
+/* channel attention (:497-508): partial [B][heads][ceil(N / 256)][1088] = per chunk G[i][j] = sum_n x[n][32 h + i] y[n][32 h + j] (1024),
+ * sum_n x[n][i]^2 (32), sum_n y[n][j]^2 (32); srk_chan_gram_floats = the partial's size in floats */
+int64_t srk_chan_gram_floats(int B, int N, int num_heads);
+int srk_chan_gram(const uint16_t* x, int ldx, const uint16_t* y, int ldy, float* partial, int B, int N, int num_heads, srk_stream_t stream);
+/* out[n][32 h + i] (+)= sum_j M[b][h][i][j] src[n][32 h + j] + diag[b][h][i] src2[n][32 h + i]   (M fp32 [B][heads][32][32]; diag optional) */
+int srk_chan_apply_mat(const float* M, const uint16_t* src, int ldsrc, const float* diag, const uint16_t* src2, int ldsrc2, uint16_t* out, int ldo,
+                       int B, int N, int num_heads, int accumulate, srk_stream_t stream);
+
 /* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
 enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1,          /* classical SR           (network_swinir.py:740-745, :813-817) */
        SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2,    /* lightweight SR         (:746-749, :818-822) */

@@ -18,7 +18,10 @@ evaluated once per block from the closed-form offset table; BatchNorm is its inf
     SGFN                        dat_arch.py:38-90   fc1, GELU, split, x1 * DWconv(LN(x2)), fc2
     DATB / ResidualGroup / DAT  dat_arch.py:531-860
 
-Inference semantics only (BatchNorm uses running statistics; the build runs DAT in eval mode).
+Eval semantics by default (BatchNorm uses running statistics).  ``train_mode(record)`` switches every BatchNorm to batch statistics
+(nn.BatchNorm2d in training, momentum 0.1: biased variance for the normalisation, unbiased for the running estimate) and records the
+updated running buffers; ``loss_and_grads`` is torch autograd over this functional model -- the training oracle pinned by
+tests/golden/g14c_dat_train.npz (the reference's own DAT in .train(), oracle/make_golden.py::gen_g14c).
 """
 from __future__ import annotations
 
@@ -113,9 +116,40 @@ def dynamic_pos_bias(sd: Dict[str, Tensor], pre: str, hs: int, wsz: int) -> Tens
 
 
 # ---- pieces ---------------------------------------------------------------------------------------------------------------
+_TRAIN: Optional[dict] = None      # None: eval; a dict: train mode, filled with the updated running statistics
+
+
+class train_mode:
+    """with train_mode(record): BatchNorm uses batch statistics; record[key] = new running_mean / running_var / num_batches_tracked."""
+
+    def __init__(self, record: dict):
+        self.record = record
+
+    def __enter__(self):
+        global _TRAIN
+        self.prev, _TRAIN = _TRAIN, self.record
+        return self.record
+
+    def __exit__(self, *exc):
+        global _TRAIN
+        _TRAIN = self.prev
+
+
 def bn_eval(x: Tensor, sd: Dict[str, Tensor], pre: str) -> Tensor:
-    """BatchNorm2d in eval mode on [B, C, ...]."""
+    """BatchNorm2d on [B, C, ...]: eval mode (running statistics) unless inside train_mode()."""
     shape = (1, -1) + (1,) * (x.ndim - 2)
+    if _TRAIN is not None:
+        dims = (0,) + tuple(range(2, x.ndim))
+        n = x.numel() // x.shape[1]
+        if n <= 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        mean = x.mean(dim=dims)
+        var = x.var(dim=dims, unbiased=False)
+        with torch.no_grad():
+            _TRAIN[pre + "running_mean"] = 0.9 * sd[pre + "running_mean"] + 0.1 * mean.detach()
+            _TRAIN[pre + "running_var"] = 0.9 * sd[pre + "running_var"] + 0.1 * var.detach() * (n / (n - 1))
+            _TRAIN[pre + "num_batches_tracked"] = sd[pre + "num_batches_tracked"] + 1
+        return (x - mean.reshape(shape)) / torch.sqrt(var.reshape(shape) + 1e-5) * sd[pre + "weight"].reshape(shape) + sd[pre + "bias"].reshape(shape)
     return ((x - sd[pre + "running_mean"].reshape(shape)) / torch.sqrt(sd[pre + "running_var"].reshape(shape) + 1e-5)
             * sd[pre + "weight"].reshape(shape) + sd[pre + "bias"].reshape(shape))
 
@@ -205,35 +239,40 @@ def sgfn(x: Tensor, H: int, W: int, sd, pre: str) -> Tensor:
     return F.linear(x1 * x2.flatten(2).transpose(1, 2), sd[pre + "fc2.weight"], sd[pre + "fc2.bias"])
 
 
-def datb(x: Tensor, H: int, W: int, sd, pre: str, cfg: DATConfig, nH: int, rg: int, b: int) -> Tensor:
+def datb(x: Tensor, H: int, W: int, sd, pre: str, cfg: DATConfig, nH: int, rg: int, b: int, drop: Optional[Tensor] = None) -> Tensor:
+    """drop: None or [2, B] DropPath factors (0 or 1 / keep) of the attention and the FFN branch (:562-563, drawn per sample)."""
     C = x.shape[-1]
     xn = F.layer_norm(x, (C,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
     if b % 2 == 0:
-        x = x + adaptive_spatial_attention(xn, H, W, sd, pre + "attn.", cfg, nH, is_shifted(rg, b))
+        a = adaptive_spatial_attention(xn, H, W, sd, pre + "attn.", cfg, nH, is_shifted(rg, b))
     else:
-        x = x + adaptive_channel_attention(xn, H, W, sd, pre + "attn.", cfg, nH)
-    return x + sgfn(F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5), H, W, sd, pre + "ffn.")
+        a = adaptive_channel_attention(xn, H, W, sd, pre + "attn.", cfg, nH)
+    x = x + (a if drop is None else a * drop[0].reshape(-1, 1, 1))
+    f = sgfn(F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5), H, W, sd, pre + "ffn.")
+    return x + (f if drop is None else f * drop[1].reshape(-1, 1, 1))
 
 
-def forward_features(f: Tensor, sd, cfg: DATConfig) -> Tensor:
+def forward_features(f: Tensor, sd, cfg: DATConfig, drop: Optional[Tensor] = None) -> Tensor:
     B, C, H, W = f.shape
     x = F.layer_norm(f.flatten(2).transpose(1, 2), (C,), sd["before_RG.1.weight"], sd["before_RG.1.bias"], 1e-5)
+    k = 0
     for li, (depth, nH) in enumerate(zip(cfg.depth, cfg.num_heads)):
         y = x
         for bi in range(depth):
-            y = datb(y, H, W, sd, f"layers.{li}.blocks.{bi}.", cfg, nH, li, bi)
+            y = datb(y, H, W, sd, f"layers.{li}.blocks.{bi}.", cfg, nH, li, bi, None if drop is None else drop[k])
+            k += 1
         y = O._resi_conv(y.transpose(1, 2).reshape(B, C, H, W), sd, f"layers.{li}.conv", cfg.resi_connection)
         x = x + y.flatten(2).transpose(1, 2)
     x = F.layer_norm(x, (C,), sd["norm.weight"], sd["norm.bias"], 1e-5)
     return x.transpose(1, 2).reshape(B, C, H, W)
 
 
-def dat_forward(sd: Dict[str, Tensor], cfg: DATConfig, x: Tensor) -> Tensor:
+def dat_forward(sd: Dict[str, Tensor], cfg: DATConfig, x: Tensor, drop: Optional[Tensor] = None) -> Tensor:
     mean = torch.tensor([0.4488, 0.4371, 0.4040], dtype=x.dtype).reshape(1, 3, 1, 1) if cfg.in_chans == 3 else torch.zeros(1, 1, 1, 1, dtype=x.dtype)
     x = (x - mean) * cfg.img_range
     s = cfg.upscale
     f = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], padding=1)
-    f = O._resi_conv(forward_features(f, sd, cfg), sd, "conv_after_body", cfg.resi_connection) + f
+    f = O._resi_conv(forward_features(f, sd, cfg, drop), sd, "conv_after_body", cfg.resi_connection) + f
     if cfg.upsampler == "pixelshuffle":
         f = F.leaky_relu(F.conv2d(f, sd["conv_before_upsample.0.weight"], sd["conv_before_upsample.0.bias"], padding=1), 0.01)
         if s & (s - 1) == 0:
@@ -247,6 +286,22 @@ def dat_forward(sd: Dict[str, Tensor], cfg: DATConfig, x: Tensor) -> Tensor:
     elif cfg.upsampler == "pixelshuffledirect":
         x = O.pixel_shuffle(F.conv2d(f, sd["upsample.0.weight"], sd["upsample.0.bias"], padding=1), s)
     return x / cfg.img_range + mean
+
+
+def loss_and_grads(sd: Dict[str, Tensor], cfg: DATConfig, x: Tensor, target: Tensor, drop: Optional[Tensor] = None):
+    """One training step's numbers: L1 loss (the training script's criterion), d loss / d parameter for every floating-point
+    non-buffer entry, and the BatchNorm running statistics after the step.  drop: [n_blocks, 2, B] DropPath factors or None."""
+    leaf = {}
+    for k, v in sd.items():
+        is_param = v.is_floating_point() and not (k.endswith("running_mean") or k.endswith("running_var") or "rpe_biases" in k or "attn_mask" in k)
+        leaf[k] = v.detach().clone().requires_grad_(True) if is_param else v
+    record: dict = {}
+    with train_mode(record):
+        out = dat_forward(leaf, cfg, x, drop)
+    loss = (out - target).abs().mean()
+    names = [k for k, v in leaf.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
+    return float(loss), out.detach(), {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(names, grads)}, record
 
 
 # ---- state_dict schema + deterministic weights -------------------------------------------------------------------------------

@@ -248,6 +248,39 @@ def gen_g14b():
     save("g14b_dat_pad_split", **arrays)
 
 
+def gen_g14c():
+    """G14c: one TRAINING step of the reference's DAT (model.train(): BatchNorm with batch statistics and running-statistic updates,
+    drop_path_rate 0 so that the step is deterministic): L1 loss, output, every parameter's gradient and the BatchNorm buffers after
+    the step, on a 32 x 32 batch of 2 (no padding) and a 24 x 40 batch of 2 (padded window frame, on-the-fly masks)."""
+    from oracle import dat_oracle as DO
+    da = import_reference("dat_arch")
+    arrays = {}
+    cfg = DO.DATConfig(**DAT_TINY)
+    sd = DO.random_state_dict(cfg, seed=16, scale=2.0)
+    arrays["weight_seed"], arrays["weight_scale"] = np.array(16), np.array(2.0)
+    arrays["weight_sha1"] = np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()])))
+    for hw in ((32, 32), (24, 40)):
+        tag = f"{hw[0]}x{hw[1]}"
+        torch.manual_seed(0)
+        m = da.DAT(**cfg.kwargs(), drop_path_rate=0.0)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        g = torch.Generator().manual_seed(hw[0] * 10 + hw[1])
+        x = torch.rand(2, 3, *hw, generator=g)
+        t = torch.rand(2, 3, hw[0] * 2, hw[1] * 2, generator=g)
+        y = m(x)
+        loss = torch.nn.functional.l1_loss(y, t)
+        loss.backward()
+        arrays[f"{tag}.x"], arrays[f"{tag}.t"], arrays[f"{tag}.y"] = x.numpy(), t.numpy(), y.detach().numpy()
+        arrays[f"{tag}.loss"] = np.array(float(loss))
+        for n, p_ in m.named_parameters():
+            arrays[f"{tag}.grad.{n}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy()
+        for n, b_ in m.named_buffers():
+            if n.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                arrays[f"{tag}.buf.{n}"] = b_.numpy()
+    save("g14c_dat_train", **arrays)
+
+
 def gen_g14():
     """G14: DAT (dat_arch.py imports with the timm stand-in).  Index tables bit-exact, a tiny DAT end to end (eval: BatchNorm with
     running statistics) incl. a shifted spatial block (rg 0, b 2), a channel-attention block and both window orientations, the
@@ -320,6 +353,8 @@ def main():
         return gen_g13()
     if "--only-g14b" in sys.argv:
         return gen_g14b()
+    if "--only-g14c" in sys.argv:
+        return gen_g14c()
     if "--only-g15" in sys.argv:
         return gen_g15()
     gen_g11()
@@ -327,6 +362,7 @@ def main():
     gen_g14()
     gen_g14b()
     gen_g15()
+    gen_g14c()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     float* pbs = reinterpret_cast<float*>(smem + OFF_PB);
     for (int i = tid; i < 9 * 32; i += 768) {
       const int tl = i >> 5, hh = tl / 3, which = tl - 3 * hh;
-      pbs[i] = p.bqkv ? p.bqkv[which * H_CA + (3 * tr + hh) * 32 + (i & 31)] * (which == 0 ? p.scale : 1.0f) : 0.f;   // bias * scale
+      pbs[i] = p.bqkv ? p.bqkv[which * H_CA + (3 * tr + hh) * 32 + (i & 31)] : 0.f;
     }
     for (int i = tid; i < 32; i += 768) pbs[9 * 32 + i] = 0.f;        // the row a dO wave adds
     const float* pbw = pbs + (it < 3 ? hl * 3 + it : 9) * 32 + 4 * g;
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {    // columns d = 16 j + 4 g .. + 3: chunk 2 j + (g >> 1), half g & 1;  (x W + b) scale = x W scale + b scale
+        for (int j = 0; j < 2; ++j) {    // columns d = 16 j + 4 g .. + 3: chunk 2 j + (g >> 1), half g & 1;  (x W + b) * scale, rounded as the forward kernel rounds it
           const float4 bq = *reinterpret_cast<const float4*>(pbw + 16 * j);
           *reinterpret_cast<uint2*>(trow + mq * (16 * 32) + (((2 * j + (g >> 1)) ^ tfr) << 3)) =
-              pack_bf4(fmaf(acc[j][0], sc, bq.x), fmaf(acc[j][1], sc, bq.y), fmaf(acc[j][2], sc, bq.z), fmaf(acc[j][3], sc, bq.w));
+              pack_bf4((acc[j][0] + bq.x) * sc, (acc[j][1] + bq.y) * sc, (acc[j][2] + bq.z) * sc, (acc[j][3] + bq.w) * sc);
         }
       }
       ABF_MARK(2);

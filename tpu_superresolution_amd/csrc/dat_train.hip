@@ -1,0 +1,692 @@
+// Training-side kernels for DAT (reference dat_arch.py), token-sized work only.  DAT's blocks are full of small per-channel or
+// per-sample functions of token REDUCTIONS (train-mode BatchNorm :301-313 / :464-476, the squeeze-excite channel interaction, the
+// channel attention's d x d matrices :497-503, the dynamic position bias MLP :93-130).  The split used here: these kernels
+// produce the reductions over tokens (fixed-order partials) and apply per-channel / per-sample coefficient vectors to token
+// tensors; the tiny functions in between (a few hundred floats) run on the host side of the C ABI (tpu_superresolution_amd/
+// dat_train.py), forward and backward.
+//
+//   chan_stats            partial[sample][chunk][0][c] = sum_t p[t][c], [1][c] = sum_t p[t][c] q[t][c]   (the pooled mean, BatchNorm statistics
+//                         with q = p; the gradients of a per-channel scale / shift with p = dy, q = x)
+//   affine_act            out = act(x * s[b][c] + t[b][c])                      (BatchNorm apply + GELU)
+//   dgelu_affine          out = dy * gelu'(x * s[c] + t[c])
+//   lincomb2              out (+)= A[b][c] p + B[b][c] q + C[b][c]              (per-sample or per-channel coefficient vectors; BatchNorm backward,
+//                         the broadcast of a pooled gradient, plain sums)
+//   mul_bwd               da = dy * b, db = dy * a                              (SpatialGate's x1 * x2, :54)
+//   dwconv3x3_wgrad       depth-wise 3x3 weight / bias gradient partials
+//   dual_gate_bwd         backward of dual_gate_combine (dat.hip): gated copies of the gradient, the channel map's gradient partials,
+//                         the spatial map's gradient through its sigmoid
+//   spatial_gate_stats / _bwd_stats / _bwd_apply   the spatial interaction (1x1 conv C -> C/16, BatchNorm, GELU, 1x1 conv -> 1, :318-323)
+//   rowln_bwd             LayerNorm backward on bf16 rows (SpatialGate.norm, :44-54)
+//   chan_gram / chan_apply_mat   the channel attention's token reductions and the application of its d x d matrices (:497-508)
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int ST_ROWS = 256;     // tokens per workgroup of the reduction passes
+
+inline int grid_cap(long long n, int block = 256, int cap = 16384) {
+  long long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// thread = (row group rg of 8, 8-channel piece); 256 threads cover 32 pieces x 8 row groups; pieces >= C8 idle
+__global__ __launch_bounds__(256) void chan_stats_kernel(const bf16_t* __restrict__ p, int ldp, const bf16_t* __restrict__ q, int ldq,
+                                                         float* __restrict__ partial, long long rows, int C8) {
+  // rows = rows of ONE sample; blockIdx.y = sample (its rows follow each other); partial [sample][chunk][2][CP]
+  __shared__ float red[2][8][256];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int CP = C8 * 8;
+  p += (long long)blockIdx.y * rows * ldp;
+  q += (long long)blockIdx.y * rows * ldq;
+  for (int c0 = 0; c0 < C8; c0 += 32) {
+    const int piece = c0 + tid % 32, rg = tid / 32;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (piece < C8) {
+      const long long r0 = (long long)chunk * ST_ROWS;
+      for (long long r = r0 + rg; r < r0 + ST_ROWS && r < rows; r += 8) {
+        const uint4 pv = *reinterpret_cast<const uint4*>(p + r * ldp + piece * 8);
+        const uint4 qv = *reinterpret_cast<const uint4*>(q + r * ldq + piece * 8);
+        const unsigned pu[4] = {pv.x, pv.y, pv.z, pv.w}, qu[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float p0, p1, q0, q1;
+          unpack_bf2(pu[e], p0, p1);
+          unpack_bf2(qu[e], q0, q1);
+          a[2 * e] += p0; a[2 * e + 1] += p1;
+          b[2 * e] += p0 * q0; b[2 * e + 1] += p1 * q1;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[0][rg][(tid % 32) * 8 + e] = a[e];
+      red[1][rg][(tid % 32) * 8 + e] = b[e];
+    }
+    __syncthreads();
+    const int c = c0 * 8 + tid;
+    if (c < CP && tid < 256) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s0 += red[0][k][tid];
+        s1 += red[1][k][tid];
+      }
+      float* dst = partial + ((long long)blockIdx.y * gridDim.x + chunk) * 2 * CP;
+      dst[c] = s0;
+      dst[CP + c] = s1;
+    }
+  }
+}
+
+// coefficient index of row t, channel c: (rps > 0 ? t / rps : 0) * CP + c
+template <int MODE>      // 0 affine (+ optional GELU), 1 dgelu_affine, 2 lincomb2
+__global__ __launch_bounds__(256) void token_elementwise_kernel(const bf16_t* __restrict__ p, int ldp, const bf16_t* __restrict__ q, int ldq,
+                                                                const float* __restrict__ A, const float* __restrict__ Bv,
+                                                                const float* __restrict__ Cv, bf16_t* __restrict__ out, int ldo,
+                                                                long long rows, int C8, int rps, int flag) {
+  const long long n = rows * C8;
+  const int CP = C8 * 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long t = i / C8;
+    const int c = (int)(i - t * C8) * 8;
+    const long long co = (rps > 0 ? (t / rps) * CP : 0) + c;
+    float pf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p) {
+      const uint4 pv = *reinterpret_cast<const uint4*>(p + t * ldp + c);
+      unpack_bf2(pv.x, pf[0], pf[1]); unpack_bf2(pv.y, pf[2], pf[3]); unpack_bf2(pv.z, pf[4], pf[5]); unpack_bf2(pv.w, pf[6], pf[7]);
+    }
+    if (q) {
+      const uint4 qv = *reinterpret_cast<const uint4*>(q + t * ldq + c);
+      unpack_bf2(qv.x, qf[0], qf[1]); unpack_bf2(qv.y, qf[2], qf[3]); unpack_bf2(qv.z, qf[4], qf[5]); unpack_bf2(qv.w, qf[6], qf[7]);
+    }
+    float o[8];
+    if constexpr (MODE == 0) {            // out = act(p * A + B)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = pf[e] * A[co + e] + Bv[co + e];
+        o[e] = flag ? gelu_f(v) : v;
+      }
+    } else if constexpr (MODE == 1) {     // out = p(dy) * gelu'(q(x) * A + B)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = pf[e] * dgelu_shared_exp(qf[e] * A[co + e] + Bv[co + e]);
+    } else if constexpr (MODE == 2) {     // out (+)= A p + B q + C   (null A / B: coefficient 1; null p / q: no such term)
+      float old[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (flag) {
+        const uint4 ov = *reinterpret_cast<const uint4*>(out + t * ldo + c);
+        unpack_bf2(ov.x, old[0], old[1]); unpack_bf2(ov.y, old[2], old[3]); unpack_bf2(ov.z, old[4], old[5]); unpack_bf2(ov.w, old[6], old[7]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = old[e] + (A ? A[co + e] * pf[e] : pf[e]) + (Bv ? Bv[co + e] * qf[e] : qf[e]) + (Cv ? Cv[co + e] : 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + t * ldo + c) =
+        make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+  }
+}
+
+// da = dy * b, db = dy * a
+__global__ __launch_bounds__(256) void mul_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ a, int lda,
+                                                      const bf16_t* __restrict__ b, int ldb, bf16_t* __restrict__ da, int ldda,
+                                                      bf16_t* __restrict__ db, int lddb, long long rows, int C8) {
+  const long long n = rows * C8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long t = i / C8;
+    const int c = (int)(i - t * C8) * 8;
+    const uint4 dv = *reinterpret_cast<const uint4*>(dy + t * lddy + c);
+    const uint4 av = *reinterpret_cast<const uint4*>(a + t * lda + c);
+    const uint4 bv = *reinterpret_cast<const uint4*>(b + t * ldb + c);
+    const unsigned du[4] = {dv.x, dv.y, dv.z, dv.w}, au[4] = {av.x, av.y, av.z, av.w}, bu[4] = {bv.x, bv.y, bv.z, bv.w};
+    unsigned oa[4], ob[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d0, d1, a0, a1, b0, b1;
+      unpack_bf2(du[e], d0, d1);
+      unpack_bf2(au[e], a0, a1);
+      unpack_bf2(bu[e], b0, b1);
+      oa[e] = pack_bf2(d0 * b0, d1 * b1);
+      ob[e] = pack_bf2(d0 * a0, d1 * a1);
+    }
+    *reinterpret_cast<uint4*>(da + t * ldda + c) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+    *reinterpret_cast<uint4*>(db + t * lddb + c) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+  }
+}
+
+// depth-wise 3x3 (pad 1) weight gradient: partial[chunk][tap][c] = sum over the chunk's pixels of dy[pix][c] x[pix + off(tap)][c],
+// partial[chunk][9][c] = sum dy.  One workgroup per (sample, 8 image rows); thread = 8-channel piece x pixel lane.
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                              float* __restrict__ partial, int H, int W, int C8) {
+  __shared__ float red[8][10][8 * 32 / 8 + 1];      // [lane][tap][channel of the piece group]  (re-used per piece group)
+  const int b = blockIdx.y, y0 = blockIdx.x * 8;
+  const int nyb = gridDim.x;
+  const int tid = threadIdx.x;
+  const int CP = C8 * 8;
+  float* dst = partial + ((long long)b * nyb + blockIdx.x) * 10 * CP;
+  for (int c0 = 0; c0 < C8; c0 += 32) {
+    const int piece = c0 + tid % 32, pl = tid / 32;        // 8 pixel lanes
+    float acc[10][8];
+#pragma unroll
+    for (int tp = 0; tp < 10; ++tp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[tp][e] = 0.f;
+    if (piece < C8) {
+      for (int yy = y0; yy < y0 + 8 && yy < H; ++yy)
+        for (int xx = pl; xx < W; xx += 8) {
+          const long long pix = ((long long)b * H + yy) * W + xx;
+          const uint4 dv = *reinterpret_cast<const uint4*>(dy + pix * lddy + piece * 8);
+          float d[8];
+          unpack_bf2(dv.x, d[0], d[1]); unpack_bf2(dv.y, d[2], d[3]); unpack_bf2(dv.z, d[4], d[5]); unpack_bf2(dv.w, d[6], d[7]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[9][e] += d[e];
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int sy = yy + tp / 3 - 1, sx = xx + tp % 3 - 1;
+            if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+              const uint4 xv = *reinterpret_cast<const uint4*>(x + (((long long)b * H + sy) * W + sx) * ldx + piece * 8);
+              float v[8];
+              unpack_bf2(xv.x, v[0], v[1]); unpack_bf2(xv.y, v[2], v[3]); unpack_bf2(xv.z, v[4], v[5]); unpack_bf2(xv.w, v[6], v[7]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[tp][e] += d[e] * v[e];
+            }
+          }
+        }
+    }
+    // combine the 8 pixel lanes of a piece (lanes tid % 32 == const): through LDS, one channel octet at a time
+    for (int e = 0; e < 8; ++e) {
+      __syncthreads();
+#pragma unroll
+      for (int tp = 0; tp < 10; ++tp) red[pl][tp][tid % 32] = acc[tp][e];
+      __syncthreads();
+      if (pl == 0 && piece < C8) {
+#pragma unroll
+        for (int tp = 0; tp < 10; ++tp) {
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s += red[k][tp][tid % 32];
+          dst[tp * CP + piece * 8 + e] = s;
+        }
+      }
+    }
+  }
+}
+
+// comb = a_chan * cg[b][c] + a_tok * tg[t]  (dual_gate_combine).  Backward: d_chan = dcomb * cg, d_tok = dcomb * tg,
+// dsmap[t] = (sum_c dcomb * a_tok) * tg (1 - tg)   [gradient w.r.t. the spatial map BEFORE its sigmoid],
+// dcg_partial[b][chunk][c] = sum over the chunk's tokens of dcomb * a_chan   [gradient w.r.t. the channel gate AFTER its sigmoid]
+__global__ __launch_bounds__(256) void dual_gate_bwd_kernel(const bf16_t* __restrict__ dcomb, const bf16_t* __restrict__ a_chan,
+                                                            const bf16_t* __restrict__ a_tok, const float* __restrict__ cgate,
+                                                            const float* __restrict__ tgate, bf16_t* __restrict__ d_chan,
+                                                            bf16_t* __restrict__ d_tok, float* __restrict__ dcg_partial,
+                                                            float* __restrict__ dsmap, int HW, int CA) {
+  // one workgroup per (sample, 64-token chunk); a wave handles 16 tokens, 4 lanes per token?  Simple form: thread = 8-channel piece
+  // x token lane; CA / 8 <= 32 pieces, 8 token lanes
+  __shared__ float red[8][256];
+  __shared__ float trow[64];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int C8 = CA / 8;
+  const int piece = tid % 32, tl = tid / 32;
+  const int t0 = chunk * 64;
+  float cg[8], accg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    cg[e] = piece < C8 ? cgate[(long long)b * CA + piece * 8 + e] : 0.f;
+    accg[e] = 0.f;
+  }
+  if (tid < 64) trow[tid] = 0.f;
+  __syncthreads();
+  for (int tt = tl; tt < 64 && t0 + tt < HW; tt += 8) {
+    const long long t = (long long)b * HW + t0 + tt;
+    float part = 0.f;
+    if (piece < C8) {
+      const long long o = t * CA + piece * 8;
+      const uint4 dv = *reinterpret_cast<const uint4*>(dcomb + o);
+      const uint4 cv = *reinterpret_cast<const uint4*>(a_chan + o);
+      const uint4 tv = *reinterpret_cast<const uint4*>(a_tok + o);
+      const float tg = tgate[t];
+      const unsigned du[4] = {dv.x, dv.y, dv.z, dv.w}, cu[4] = {cv.x, cv.y, cv.z, cv.w}, tu[4] = {tv.x, tv.y, tv.z, tv.w};
+      unsigned oc[4], ot[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d0, d1, c0, c1, k0, k1;
+        unpack_bf2(du[e], d0, d1);
+        unpack_bf2(cu[e], c0, c1);
+        unpack_bf2(tu[e], k0, k1);
+        oc[e] = pack_bf2(d0 * cg[2 * e], d1 * cg[2 * e + 1]);
+        ot[e] = pack_bf2(d0 * tg, d1 * tg);
+        accg[2 * e] += d0 * c0;
+        accg[2 * e + 1] += d1 * c1;
+        part += d0 * k0 + d1 * k1;
+      }
+      *reinterpret_cast<uint4*>(d_chan + o) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
+      *reinterpret_cast<uint4*>(d_tok + o) = make_uint4(ot[0], ot[1], ot[2], ot[3]);
+    }
+    // sum over the 32 pieces of this token: the 32 lanes tid % 32 of token lane tl are half a wave
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+    part += __shfl_xor(part, 8, 64); part += __shfl_xor(part, 16, 64);
+    if (piece == 0) trow[tt] = part;
+  }
+  __syncthreads();
+  if (tid < 64 && t0 + tid < HW) {
+    const long long t = (long long)b * HW + t0 + tid;
+    const float tg = tgate[t];
+    dsmap[t] = trow[tid] * tg * (1.0f - tg);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __syncthreads();
+    red[tl][piece * 8 + e] = accg[e];
+  }
+  __syncthreads();
+  if (tid < CA) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][tid];
+    dcg_partial[((long long)b * gridDim.x + chunk) * CA + tid] = s;
+  }
+}
+
+// ---- spatial interaction: y1 = W0 x + b0 (S <= 16 outputs), z = y1 * s + t (BatchNorm), a = gelu(z), smap = w3 . a + b3 ---------------
+// One thread per token (the S x C weights staged in LDS); reductions over the workgroup's tokens by warp shuffles + LDS.
+template <int WHAT>      // 0: stats of y1 (sum, sum sq)   1: backward stats (sum dz, sum dz y1, sum dsmap a, sum dsmap)
+                         // 2: backward apply: dy1 = A dz + B y1 + C -> dx[t][c] (+)= sum_s W0[s][c] dy1[s]; dW0 / db0 partials
+__global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ W0,
+                                                                 const float* __restrict__ b0, const float* __restrict__ sc,
+                                                                 const float* __restrict__ sh, const float* __restrict__ w3,
+                                                                 const float* __restrict__ dsmap, const float* __restrict__ cA,
+                                                                 const float* __restrict__ cB, const float* __restrict__ cC,
+                                                                 bf16_t* __restrict__ dx, int lddx, int accumulate,
+                                                                 float* __restrict__ partial, long long rows, int C, int S) {
+  extern __shared__ float sm[];
+  float* Wl = sm;                        // [S][C]
+  float* red = sm + S * C;               // [256][4 * 16] max
+  const int tid = threadIdx.x;
+  for (int i = tid; i < S * C; i += 256) Wl[i] = W0[i];
+  __syncthreads();
+  const long long t = (long long)blockIdx.x * 256 + tid;
+  const bool ok = t < rows;
+  float y1[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) y1[s] = s < S ? b0[s] : 0.f;
+  if (ok) {
+    for (int c = 0; c < C; c += 8) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(x + t * ldx + c);
+      float v[8];
+      unpack_bf2(xv.x, v[0], v[1]); unpack_bf2(xv.y, v[2], v[3]); unpack_bf2(xv.z, v[4], v[5]); unpack_bf2(xv.w, v[6], v[7]);
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (s < S) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y1[s] = fmaf(Wl[s * C + c + e], v[e], y1[s]);
+        }
+    }
+  }
+  constexpr int NV = WHAT == 0 ? 2 : (WHAT == 1 ? 4 : 1);
+  float vals[NV][16];
+  float dy1[16];
+  if constexpr (WHAT == 0) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      vals[0][s] = ok ? y1[s] : 0.f;
+      vals[1][s] = ok ? y1[s] * y1[s] : 0.f;
+    }
+  } else {
+    const float ds = ok ? dsmap[t] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float z = y1[s] * (s < S ? sc[s] : 0.f) + (s < S ? sh[s] : 0.f);
+      const float a = gelu_f(z);
+      const float dz = s < S ? ds * w3[s] * dgelu_shared_exp(z) : 0.f;       // d a = dsmap * w3, through GELU
+      if constexpr (WHAT == 1) {
+        vals[0][s] = dz;
+        vals[1][s] = dz * y1[s];
+        vals[2][s] = s < S ? ds * a : 0.f;
+        vals[3][s] = s == 0 ? ds : 0.f;
+      } else {
+        dy1[s] = (ok && s < S) ? cA[s] * dz + cB[s] * y1[s] + cC[s] : 0.f;
+        vals[0][s] = dy1[s];
+      }
+    }
+  }
+  // workgroup sums of vals -> partial[block][NV][16]
+  float* mine = red + tid * (NV * 16);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) mine[k * 16 + s] = vals[k][s];
+  __syncthreads();
+  if (tid < NV * 16) {
+    float s = 0.f;
+    for (int k = 0; k < 256; ++k) s += red[k * (NV * 16) + tid];
+    const int base = WHAT == 2 ? 16 * (C + 1) : NV * 16;
+    partial[(long long)blockIdx.x * base + (WHAT == 2 ? 16 * C : 0) + tid] = s;       // WHAT 2: db0 partial behind the dW0 partial
+  }
+  if constexpr (WHAT == 2) {
+    // d x = W0^T dy1 (per token); dW0[s][c] partial = sum over the workgroup's tokens of dy1[s] x[c]
+    if (ok) {
+      for (int c = 0; c < C; c += 8) {
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (accumulate) {
+          const uint4 ov = *reinterpret_cast<const uint4*>(dx + t * lddx + c);
+          unpack_bf2(ov.x, o[0], o[1]); unpack_bf2(ov.y, o[2], o[3]); unpack_bf2(ov.z, o[4], o[5]); unpack_bf2(ov.w, o[6], o[7]);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          if (s < S) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(Wl[s * C + c + e], dy1[s], o[e]);
+          }
+        *reinterpret_cast<uint4*>(dx + t * lddx + c) =
+            make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+      }
+    }
+    // dW0 partial: stage dy1 of the 256 tokens in LDS, then thread = channel pair walks the tokens
+    __syncthreads();
+    float* dyl = red;                     // [256][16]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dyl[tid * 16 + s] = dy1[s];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float acc[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+      const long long t0 = (long long)blockIdx.x * 256;
+      for (int k = 0; k < 256 && t0 + k < rows; ++k) {
+        const float xv = bf2f(x[(t0 + k) * ldx + c]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = fmaf(dyl[k * 16 + s], xv, acc[s]);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) partial[(long long)blockIdx.x * 16 * (C + 1) + s * C + c] = acc[s];
+    }
+  }
+}
+
+// LayerNorm backward on bf16 rows: x [rows][ldx] (first C columns normalised), dy [rows][lddy]; dx bf16; dgamma / dbeta partials per
+// workgroup [block][2][C].  16 lanes per row (4 rows per wave), each lane C / 16 (rounded up) columns in steps of 16.
+__global__ __launch_bounds__(256) void rowln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma, bf16_t* __restrict__ dx, int lddx,
+                                                        float* __restrict__ partial, long long rows, int C, int CPo) {
+  extern __shared__ float sm[];          // [2][C] per-workgroup dgamma / dbeta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, sub = lane >> 4;
+  for (int i = tid; i < 2 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const float invC = 1.0f / (float)C;
+  for (long long m = ((long long)blockIdx.x * 4 + wave) * 4 + sub; m < rows; m += (long long)gridDim.x * 16) {
+    float s = 0.f, q = 0.f;
+    for (int c = j; c < C; c += 16) {
+      const float v = bf2f(x[m * ldx + c]);
+      s += v;
+      q += v * v;
+    }
+    const float mean = wave_sum16(s) * invC;
+    const float var = fmaxf(wave_sum16(q) * invC - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = j; c < C; c += 16) {
+      const float xh = (bf2f(x[m * ldx + c]) - mean) * rstd;
+      const float dg = bf2f(dy[m * lddy + c]) * gamma[c];
+      s1 += dg;
+      s2 += dg * xh;
+    }
+    s1 = wave_sum16(s1) * invC;
+    s2 = wave_sum16(s2) * invC;
+    for (int c = j; c < CPo; c += 16) {
+      float o = 0.f;
+      if (c < C) {
+        const float xh = (bf2f(x[m * ldx + c]) - mean) * rstd;
+        const float d = bf2f(dy[m * lddy + c]);
+        o = rstd * (d * gamma[c] - s1 - xh * s2);
+        atomicAdd(&sm[c], d * xh);
+        atomicAdd(&sm[C + c], d);
+      }
+      dx[m * lddx + c] = f2bf(o);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) partial[(long long)blockIdx.x * 2 * C + i] = sm[i];
+}
+
+// ---- channel attention ------------------------------------------------------------------------------------------------------------------
+constexpr int TG_CH = 256;            // tokens per Gram chunk
+constexpr int TG_SZ = 32 * 32 + 64;   // partial: G[32][32] = sum_n x[n][i] y[n][j], sum_n x[n][i]^2, sum_n y[n][j]^2
+
+// grid (chunks, heads, B): x, y bf16 [B*N][ld*], head h at column 32 h of each
+__global__ __launch_bounds__(256) void chan_gram2_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
+                                                         float* __restrict__ partial, int N) {
+  __shared__ float xs[TG_CH][33], ys[TG_CH][33];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int n0 = chunk * TG_CH;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < TG_CH * 8; i += 256) {
+    const int r = i >> 3, c = (i & 7) * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (n0 + r < N) {
+      const long long row = (long long)b * N + n0 + r;
+      const uint2 xu = *reinterpret_cast<const uint2*>(x + row * ldx + h * 32 + c);
+      const uint2 yu = *reinterpret_cast<const uint2*>(y + row * ldy + h * 32 + c);
+      unpack_bf2(xu.x, a0, a1); unpack_bf2(xu.y, a2, a3);
+      unpack_bf2(yu.x, b0, b1); unpack_bf2(yu.y, b2, b3);
+    }
+    xs[r][c] = a0; xs[r][c + 1] = a1; xs[r][c + 2] = a2; xs[r][c + 3] = a3;
+    ys[r][c] = b0; ys[r][c + 1] = b1; ys[r][c + 2] = b2; ys[r][c + 3] = b3;
+  }
+  __syncthreads();
+  float* o = partial + (((long long)b * gridDim.y + h) * gridDim.x + chunk) * TG_SZ;
+  for (int p = tid; p < 32 * 32; p += 256) {
+    const int i = p >> 5, j = p & 31;
+    float s = 0.f;
+    for (int r = 0; r < TG_CH; ++r) s = fmaf(xs[r][i], ys[r][j], s);
+    o[p] = s;
+  }
+  if (tid < 64) {
+    const int c = tid & 31;
+    float s = 0.f;
+    if (tid < 32) for (int r = 0; r < TG_CH; ++r) s = fmaf(xs[r][c], xs[r][c], s);
+    else for (int r = 0; r < TG_CH; ++r) s = fmaf(ys[r][c], ys[r][c], s);
+    o[1024 + tid] = s;
+  }
+}
+
+// out[n][32 h + i] (+)= sum_j M[b][h][i][j] src[n][32 h + j]  (+ dg[b][h][i] * src2[n][32 h + i]) : fp32 matrices, fp32 accumulation
+__global__ __launch_bounds__(256) void chan_apply_mat_kernel(const float* __restrict__ M, const bf16_t* __restrict__ src, int lds_,
+                                                             const float* __restrict__ dg, const bf16_t* __restrict__ src2, int lds2,
+                                                             bf16_t* __restrict__ out, int ldo, int nH, int N, int accumulate) {
+  __shared__ float Ml[32][33];
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += 256) Ml[i >> 5][i & 31] = M[((long long)b * nH + h) * 1024 + i];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= N) return;
+  const long long row = (long long)b * N + n;
+  float v[32];
+#pragma unroll
+  for (int c = 0; c < 32; c += 8) {
+    const uint4 sv = *reinterpret_cast<const uint4*>(src + row * lds_ + h * 32 + c);
+    unpack_bf2(sv.x, v[c], v[c + 1]); unpack_bf2(sv.y, v[c + 2], v[c + 3]); unpack_bf2(sv.z, v[c + 4], v[c + 5]); unpack_bf2(sv.w, v[c + 6], v[c + 7]);
+  }
+#pragma unroll
+  for (int c = 0; c < 32; c += 8) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s = fmaf(Ml[c + e][j], v[j], s);
+      o[e] = s;
+    }
+    if (dg) {
+      const uint4 s2 = *reinterpret_cast<const uint4*>(src2 + row * lds2 + h * 32 + c);
+      float w[8];
+      unpack_bf2(s2.x, w[0], w[1]); unpack_bf2(s2.y, w[2], w[3]); unpack_bf2(s2.z, w[4], w[5]); unpack_bf2(s2.w, w[6], w[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += dg[((long long)b * nH + h) * 32 + c + e] * w[e];
+    }
+    if (accumulate) {
+      const uint4 ov = *reinterpret_cast<const uint4*>(out + row * ldo + h * 32 + c);
+      float w[8];
+      unpack_bf2(ov.x, w[0], w[1]); unpack_bf2(ov.y, w[2], w[3]); unpack_bf2(ov.z, w[4], w[5]); unpack_bf2(ov.w, w[6], w[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += w[e];
+    }
+    *reinterpret_cast<uint4*>(out + row * ldo + h * 32 + c) =
+        make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+  }
+}
+
+}  // namespace
+
+int srk_launch_win_attn_bwd_padded(const bf16_t* qkv, int ldq, int CA, const float* bias, const bf16_t* dout, int ldo, bf16_t* dqkv,
+                                   float* dbias, int B, int H, int W, int Hp, int Wp, int wh, int ww, int sy, int sx, int nH, float scale,
+                                   hipStream_t stream);
+
+extern "C" {
+
+#define REQP(c, ...) SRK_REQUIRE(c, SRK_E_SHAPE, __VA_ARGS__)
+
+int64_t srk_chan_stats_chunks(int64_t rows) { return rows <= 0 ? 0 : (rows + ST_ROWS - 1) / ST_ROWS; }
+
+int srk_chan_stats(const uint16_t* p, int ldp, const uint16_t* q, int ldq, float* partial, int samples, int64_t rows_per_sample, int C8,
+                   srk_stream_t stream) {
+  SRK_REQUIRE(p && q && partial, SRK_E_NULL, "chan_stats: null pointer");
+  REQP(samples > 0 && samples <= 65535 && rows_per_sample > 0 && C8 > 0 && C8 <= 64 && ldp % 8 == 0 && ldq % 8 == 0, "chan_stats: bad shape");
+  hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)srk_chan_stats_chunks(rows_per_sample), samples), dim3(256), 0, (hipStream_t)stream, p, ldp,
+                     q, ldq, partial, (long long)rows_per_sample, C8);
+  return srk_check_launch("chan_stats");
+}
+
+int srk_affine_act_bf16(const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out, int ldo, int64_t rows, int C8,
+                        int rows_per_sample, int act, srk_stream_t stream) {
+  SRK_REQUIRE(x && scale && shift && out, SRK_E_NULL, "affine_act: null pointer");
+  REQP(rows > 0 && C8 > 0 && ldx % 8 == 0 && ldo % 8 == 0, "affine_act: bad shape");
+  hipLaunchKernelGGL(token_elementwise_kernel<0>, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16_t*)nullptr, 0,
+                     scale, shift, (const float*)nullptr, out, ldo, (long long)rows, C8, rows_per_sample, act);
+  return srk_check_launch("affine_act");
+}
+
+int srk_dgelu_affine_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out,
+                          int ldo, int64_t rows, int C8, srk_stream_t stream) {
+  SRK_REQUIRE(dy && x && scale && shift && out, SRK_E_NULL, "dgelu_affine: null pointer");
+  REQP(rows > 0 && C8 > 0 && lddy % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "dgelu_affine: bad shape");
+  hipLaunchKernelGGL(token_elementwise_kernel<1>, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, scale, shift,
+                     (const float*)nullptr, out, ldo, (long long)rows, C8, 0, 0);
+  return srk_check_launch("dgelu_affine");
+}
+
+int srk_lincomb2_bf16(const uint16_t* p, int ldp, const uint16_t* q, int ldq, const float* A, const float* Bc, const float* Cc, uint16_t* out,
+                      int ldo, int64_t rows, int C8, int rows_per_sample, int accumulate, srk_stream_t stream) {
+  SRK_REQUIRE(out, SRK_E_NULL, "lincomb2: null pointer");
+  REQP(rows > 0 && C8 > 0 && ldo % 8 == 0 && (p == nullptr || ldp % 8 == 0) && (q == nullptr || ldq % 8 == 0) && (A == nullptr || p != nullptr) &&
+           (Bc == nullptr || q != nullptr),
+       "lincomb2: bad shape");
+  hipLaunchKernelGGL(token_elementwise_kernel<2>, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, p, ldp, q, ldq, A, Bc, Cc, out,
+                     ldo, (long long)rows, C8, rows_per_sample, accumulate);
+  return srk_check_launch("lincomb2");
+}
+
+int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* da, int ldda, uint16_t* db,
+                     int lddb, int64_t rows, int C8, srk_stream_t stream) {
+  SRK_REQUIRE(dy && a && b && da && db, SRK_E_NULL, "mul_bwd: null pointer");
+  REQP(rows > 0 && C8 > 0 && (lddy | lda | ldb | ldda | lddb) % 8 == 0, "mul_bwd: bad shape");
+  hipLaunchKernelGGL(mul_bwd_kernel, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, dy, lddy, a, lda, b, ldb, da, ldda, db, lddb,
+                     (long long)rows, C8);
+  return srk_check_launch("mul_bwd");
+}
+
+int srk_dwconv3x3_wgrad(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, float* partial, int B, int H, int W, int C8,
+                        srk_stream_t stream) {
+  SRK_REQUIRE(dy && x && partial, SRK_E_NULL, "dwconv3x3_wgrad: null pointer");
+  REQP(B > 0 && H > 0 && W > 0 && C8 > 0 && C8 <= 64 && lddy % 8 == 0 && ldx % 8 == 0, "dwconv3x3_wgrad: bad shape");
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((H + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, partial, H, W, C8);
+  return srk_check_launch("dwconv3x3_wgrad");
+}
+
+int srk_dual_gate_bwd(const uint16_t* dcomb, const uint16_t* a_chan, const uint16_t* a_tok, const float* cgate, const float* tgate,
+                      uint16_t* d_chan, uint16_t* d_tok, float* dcg_partial, float* dsmap, int B, int HW, int CA, srk_stream_t stream) {
+  SRK_REQUIRE(dcomb && a_chan && a_tok && cgate && tgate && d_chan && d_tok && dcg_partial && dsmap, SRK_E_NULL, "dual_gate_bwd: null pointer");
+  REQP(B > 0 && HW > 0 && CA > 0 && CA <= 256 && CA % 8 == 0, "dual_gate_bwd: bad shape");
+  hipLaunchKernelGGL(dual_gate_bwd_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, dcomb, a_chan, a_tok, cgate, tgate, d_chan,
+                     d_tok, dcg_partial, dsmap, HW, CA);
+  return srk_check_launch("dual_gate_bwd");
+}
+
+// what: 0 forward statistics, 1 backward statistics, 2 backward apply (see spatial_gate_train_kernel)
+int srk_spatial_gate_train(int what, const uint16_t* x, int ldx, const float* W0, const float* b0, const float* bn_scale, const float* bn_shift,
+                           const float* w3, const float* dsmap, const float* cA, const float* cB, const float* cC, uint16_t* dx, int lddx,
+                           int accumulate, float* partial, int64_t rows, int C, int S, srk_stream_t stream) {
+  SRK_REQUIRE(x && W0 && b0 && partial, SRK_E_NULL, "spatial_gate_train: null pointer");
+  REQP(rows > 0 && C > 0 && C % 8 == 0 && C <= 256 && S > 0 && S <= 16 && ldx % 8 == 0 && what >= 0 && what <= 2, "spatial_gate_train: bad shape");
+  SRK_REQUIRE(what == 0 || (bn_scale && bn_shift && w3 && dsmap), SRK_E_NULL, "spatial_gate_train: backward operands missing");
+  SRK_REQUIRE(what != 2 || (cA && cB && cC && dx && lddx % 8 == 0), SRK_E_NULL, "spatial_gate_train: apply operands missing");
+  const unsigned grid = (unsigned)((rows + 255) / 256);
+  const size_t lds = (size_t)(S * C + 256 * 64) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess) {
+      srk_set_error("spatial_gate_train: cannot reserve LDS");
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (what == 0)
+    hipLaunchKernelGGL(spatial_gate_train_kernel<0>, dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3, dsmap, cA, cB, cC, dx,
+                       lddx, accumulate, partial, (long long)rows, C, S);
+  else if (what == 1)
+    hipLaunchKernelGGL(spatial_gate_train_kernel<1>, dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3, dsmap, cA, cB, cC, dx,
+                       lddx, accumulate, partial, (long long)rows, C, S);
+  else
+    hipLaunchKernelGGL(spatial_gate_train_kernel<2>, dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3, dsmap, cA, cB, cC, dx,
+                       lddx, accumulate, partial, (long long)rows, C, S);
+  return srk_check_launch("spatial_gate_train");
+}
+
+int64_t srk_rowln_bwd_blocks(int64_t rows) {
+  const int64_t g = (rows + 15) / 16;
+  return g < 1 ? 1 : (g > 4096 ? 4096 : g);
+}
+
+int srk_rowln_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* gamma, uint16_t* dx, int lddx, float* partial,
+                       int64_t rows, int C, int CP_out, srk_stream_t stream) {
+  SRK_REQUIRE(dy && x && gamma && dx && partial, SRK_E_NULL, "rowln_bwd: null pointer");
+  REQP(rows > 0 && C > 0 && C <= CP_out && C <= 1024, "rowln_bwd: bad shape");
+  hipLaunchKernelGGL(rowln_bwd_kernel, dim3((unsigned)srk_rowln_bwd_blocks(rows)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, lddy, x,
+                     ldx, gamma, dx, lddx, partial, (long long)rows, C, CP_out);
+  return srk_check_launch("rowln_bwd");
+}
+
+int64_t srk_chan_gram_floats(int B, int N, int num_heads) { return (int64_t)B * num_heads * ((N + TG_CH - 1) / TG_CH) * TG_SZ; }
+
+// partial [B][heads][chunks][1088]: G = sum_n x[n][i] y[n][j], sum x^2, sum y^2 per 256-token chunk (the caller sums the chunks)
+int srk_chan_gram(const uint16_t* x, int ldx, const uint16_t* y, int ldy, float* partial, int B, int N, int num_heads, srk_stream_t stream) {
+  SRK_REQUIRE(x && y && partial, SRK_E_NULL, "chan_gram: null pointer");
+  REQP(B > 0 && N > 0 && num_heads > 0 && ldx % 4 == 0 && ldy % 4 == 0, "chan_gram: bad shape");
+  hipLaunchKernelGGL(chan_gram2_kernel, dim3((N + TG_CH - 1) / TG_CH, num_heads, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, partial, N);
+  return srk_check_launch("chan_gram");
+}
+
+// out[n][32 h + i] (+)= sum_j M[b][h][i][j] src[n][32 h + j] + diag[b][h][i] src2[n][32 h + i]
+int srk_chan_apply_mat(const float* M, const uint16_t* src, int ldsrc, const float* diag, const uint16_t* src2, int ldsrc2, uint16_t* out, int ldo,
+                       int B, int N, int num_heads, int accumulate, srk_stream_t stream) {
+  SRK_REQUIRE(M && src && out && (diag == nullptr || src2 != nullptr), SRK_E_NULL, "chan_apply_mat: null pointer");
+  REQP(B > 0 && N > 0 && num_heads > 0 && ldsrc % 8 == 0 && ldo % 8 == 0 && (src2 == nullptr || ldsrc2 % 8 == 0), "chan_apply_mat: bad shape");
+  hipLaunchKernelGGL(chan_apply_mat_kernel, dim3((N + 255) / 256, num_heads, B), dim3(256), 0, (hipStream_t)stream, M, src, ldsrc, diag, src2, ldsrc2,
+                     out, ldo, num_heads, N, accumulate);
+  return srk_check_launch("chan_apply_mat");
+}
+
+int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, const uint16_t* d_out, int ldo, uint16_t* d_qkv,
+                                 float* d_bias, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x, int num_heads,
+                                 float scale, srk_stream_t stream) {
+  return srk_launch_win_attn_bwd_padded(qkv, ldq, CA, bias, d_out, ldo, d_qkv, d_bias, B, H, W, Hp, Wp, wh, ww, shift_y, shift_x, num_heads, scale,
+                                        (hipStream_t)stream);
+}
+
+}  // extern "C"
