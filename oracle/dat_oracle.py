@@ -301,7 +301,7 @@ def loss_and_grads(sd: Dict[str, Tensor], cfg: DATConfig, x: Tensor, target: Ten
     loss = (out - target).abs().mean()
     names = [k for k, v in leaf.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
-    return float(loss), out.detach(), {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(names, grads)}, record
+    return float(loss.detach()), out.detach(), {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(names, grads)}, record
 
 
 # ---- state_dict schema + deterministic weights -------------------------------------------------------------------------------

@@ -142,7 +142,7 @@ def test_dat_errors_are_loud():
     m = T.DAT(**cfg.kwargs())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.eval()(torch.rand(1, 3, 64, 64))
-    with pytest.raises(NotImplementedError, match="eval mode only"):
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):     # torch's BatchNorm error, batch of one
         m.cuda().train()(torch.rand(1, 3, 64, 64, device="cuda"))
     with pytest.raises(NotImplementedError, match="split_size"):
         T.DAT(**{**cfg.kwargs(), "split_size": [8, 8]}).cuda().eval()(torch.rand(1, 3, 64, 64, device="cuda"))
@@ -180,3 +180,311 @@ def test_dat_cfg5_width_at_a_padded_size_vs_oracle():
         ref = DO.dat_forward(sd, cfg, x)
     err = float((y - ref).abs().max())
     assert y.shape == ref.shape and err <= 5e-3 * max(1.0, float(ref.abs().max())), err
+
+
+# ---- training (csrc/dat_train.hip, csrc/attn_rect_bwd.hip, dat_train.py) -------------------------------------------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_dat_train_token_kernels_vs_torch():
+    """chan_stats, affine_act, dgelu_affine, lincomb2, mul_bwd, dwconv3x3_wgrad, dual_gate_bwd, rowln_bwd against fp32 torch (autograd
+    where it applies) on the same bf16 inputs."""
+    check, L = _lib()
+    g = torch.Generator().manual_seed(1)
+    B, H, W, C = 2, 12, 20, 40
+    HW, T = H * W, B * H * W
+    ld = 64
+    p, q = _bf(torch.randn(T, ld, generator=g)), _bf(torch.randn(T, ld, generator=g))
+    pd, qd = p.cuda(), q.cuda()
+    nck = int(L.srk_chan_stats_chunks(HW))
+    part = torch.empty(B, nck, 2, C, device="cuda")
+    check(L.srk_chan_stats(pd.data_ptr() + 16, ld, qd.data_ptr() + 16, ld, part.data_ptr(), B, HW, C // 8, _st()))
+    got = part.sum(1).cpu()
+    pf, qf = p.float()[:, 8:8 + C].reshape(B, HW, C), q.float()[:, 8:8 + C].reshape(B, HW, C)
+    assert _rel(got[:, 0], pf.sum(1)) <= 1e-5 and _rel(got[:, 1], (pf * qf).sum(1)) <= 1e-5
+    # affine (+ GELU) with per-sample vectors; dgelu_affine; lincomb2
+    A, Bv, Cv = torch.randn(B, C, generator=g), torch.randn(B, C, generator=g), torch.randn(B, C, generator=g)
+    Ad, Bd, Cd = A.cuda(), Bv.cuda(), Cv.cuda()
+    out = torch.zeros(T, ld, dtype=torch.bfloat16, device="cuda")
+    check(L.srk_affine_act_bf16(pd.data_ptr() + 16, ld, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), ld, T, C // 8, HW, 1, _st()))
+    want = F.gelu(pf * A[:, None] + Bv[:, None]).reshape(T, C)
+    assert float((out.cpu().float()[:, :C] - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    check(L.srk_dgelu_affine_bf16(qd.data_ptr() + 16, ld, pd.data_ptr() + 16, ld, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), ld, T, C // 8, _st()))
+    z = (pf.reshape(T, C) * A[0] + Bv[0]).requires_grad_(True)
+    F.gelu(z).backward(qf.reshape(T, C))
+    assert _rel(out.cpu().float()[:, :C], z.grad) <= 1e-2
+    acc = _bf(torch.randn(T, ld, generator=g))
+    accd = acc.cuda()
+    check(L.srk_lincomb2_bf16(pd.data_ptr() + 16, ld, qd.data_ptr() + 16, ld, Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), accd.data_ptr(), ld, T,
+                              C // 8, HW, 1, _st()))
+    want = acc.float()[:, :C] + (pf * A[:, None] + qf * Bv[:, None] + Cv[:, None]).reshape(T, C)
+    assert float((accd.cpu().float()[:, :C] - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    check(L.srk_lincomb2_bf16(pd.data_ptr() + 16, ld, None, 0, None, None, None, accd.data_ptr(), ld, T, C // 8, 0, 0, _st()))       # plain copy
+    assert torch.equal(accd.cpu()[:, :C], p[:, 8:8 + C])
+    # mul_bwd
+    da, db = torch.zeros(T, ld, dtype=torch.bfloat16, device="cuda"), torch.zeros(T, ld, dtype=torch.bfloat16, device="cuda")
+    check(L.srk_mul_bwd_bf16(accd.data_ptr(), ld, pd.data_ptr() + 16, ld, qd.data_ptr() + 16, ld, da.data_ptr(), ld, db.data_ptr(), ld, T, C // 8, _st()))
+    dyf = accd.cpu().float()[:, :C]
+    assert _rel(da.cpu().float()[:, :C], dyf * qf.reshape(T, C)) <= 5e-3 and _rel(db.cpu().float()[:, :C], dyf * pf.reshape(T, C)) <= 5e-3
+    # depth-wise 3x3 weight / bias gradient
+    wt = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    bs = torch.zeros(C, requires_grad=True)
+    xi = pf.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    F.conv2d(xi, wt, bs, padding=1, groups=C).backward(qf.reshape(B, H, W, C).permute(0, 3, 1, 2))
+    part = torch.empty(B, (H + 7) // 8, 10, C, device="cuda")
+    check(L.srk_dwconv3x3_wgrad(qd.data_ptr() + 16, ld, pd.data_ptr() + 16, ld, part.data_ptr(), B, H, W, C // 8, _st()))
+    got = part.sum((0, 1)).cpu()
+    assert _rel(got[:9].t().reshape(C, 1, 3, 3), wt.grad) <= 1e-5 and _rel(got[9], bs.grad) <= 1e-5
+    # dual gate backward
+    CA = 64
+    a1, a2, dc = (_bf(torch.randn(T, CA, generator=g)) for _ in range(3))
+    cg, smap = torch.rand(B, CA, generator=g), torch.randn(T, generator=g)
+    a1f, a2f = a1.float().requires_grad_(True), a2.float().requires_grad_(True)
+    cgf, smf = cg.clone().requires_grad_(True), smap.clone().requires_grad_(True)
+    comb = a1f.reshape(B, HW, CA) * cgf[:, None] + a2f.reshape(B, HW, CA) * torch.sigmoid(smf).reshape(B, HW, 1)
+    comb.backward(dc.float().reshape(B, HW, CA))
+    tg = torch.sigmoid(smap).cuda()
+    d1, d2 = torch.empty(T, CA, dtype=torch.bfloat16, device="cuda"), torch.empty(T, CA, dtype=torch.bfloat16, device="cuda")
+    dcgp, dsm = torch.empty(B, (HW + 63) // 64, CA, device="cuda"), torch.empty(T, device="cuda")
+    dcd, a1d, a2d, cgd = dc.cuda(), a1.cuda(), a2.cuda(), cg.cuda()
+    check(L.srk_dual_gate_bwd(dcd.data_ptr(), a1d.data_ptr(), a2d.data_ptr(), cgd.data_ptr(), tg.data_ptr(), d1.data_ptr(), d2.data_ptr(),
+                              dcgp.data_ptr(), dsm.data_ptr(), B, HW, CA, _st()))
+    assert _rel(d1.cpu().float(), a1f.grad) <= 5e-3 and _rel(d2.cpu().float(), a2f.grad) <= 5e-3
+    assert _rel(dcgp.sum(1).cpu(), cgf.grad) <= 1e-5 and _rel(dsm.cpu(), smf.grad) <= 1e-5
+    # LayerNorm backward on a bf16 row slice
+    rows, Cn, CPn = 300, 90, 128
+    h = _bf(torch.randn(rows, 256, generator=g))
+    dyl = _bf(torch.randn(rows, CPn, generator=g))
+    gm = torch.rand(Cn, generator=g) + 0.5
+    hx = h.float()[:, 128:128 + Cn].requires_grad_(True)
+    gmr, btr = gm.clone().requires_grad_(True), torch.zeros(Cn, requires_grad=True)
+    F.layer_norm(hx, (Cn,), gmr, btr, 1e-5).backward(dyl.float()[:, :Cn])
+    dxl = torch.full((rows, 256), 7.0, dtype=torch.bfloat16, device="cuda")
+    nb = int(L.srk_rowln_bwd_blocks(rows))
+    part = torch.empty(nb, 2, Cn, device="cuda")
+    dyd, hd_, gmd = dyl.cuda(), h.cuda(), gm.cuda()
+    check(L.srk_rowln_bwd_bf16(dyd.data_ptr(), CPn, hd_.data_ptr() + 128 * 2, 256, gmd.data_ptr(), dxl.data_ptr() + 128 * 2, 256, part.data_ptr(), rows,
+                               Cn, CPn, _st()))
+    got = dxl.cpu().float()
+    assert _rel(got[:, 128:128 + Cn], hx.grad) <= 1e-2 and float(got[:, 128 + Cn:].abs().max()) == 0.0 and float(got[:, :128].min()) == 7.0
+    ps = part.sum(0).cpu()
+    assert _rel(ps[0], gmr.grad) <= 1e-4 and _rel(ps[1], btr.grad) <= 1e-4
+
+
+def test_dat_spatial_gate_train_passes_vs_autograd():
+    """The three passes of the spatial interaction in training (statistics, backward statistics, backward apply) with the closed-form
+    BatchNorm coefficients of dat_train.py against torch autograd of conv1x1 -> BatchNorm(train) -> GELU -> conv1x1."""
+    from tpu_superresolution_amd import dat_train as DT
+    check, L = _lib()
+    g = torch.Generator().manual_seed(2)
+    T, CA, S = 700, 128, 7
+    x = _bf(torch.randn(T, CA, generator=g))
+    W0, b0 = torch.randn(S, CA, generator=g) * 0.1, torch.randn(S, generator=g) * 0.1
+    gam, bet, w3 = torch.rand(S, generator=g) + 0.5, torch.randn(S, generator=g) * 0.1, torch.randn(S, generator=g)
+    dsm = torch.randn(T, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x.float(), W0, b0, gam, bet, w3)]
+    xf, W0r, b0r, gr, br, w3r = leaves
+    y1 = xf @ W0r.t() + b0r
+    z = (y1 - y1.mean(0)) / torch.sqrt(y1.var(0, unbiased=False) + 1e-5) * gr + br
+    smap = F.gelu(z) @ w3r
+    smap.backward(dsm)
+    xd, W0d, b0d, w3d, dsd = x.cuda(), W0.cuda(), b0.cuda(), w3.cuda(), dsm.cuda()
+    nblk = (T + 255) // 256
+    part = torch.empty(nblk, 2, 16, device="cuda")
+    check(L.srk_spatial_gate_train(0, xd.data_ptr(), CA, W0d.data_ptr(), b0d.data_ptr(), None, None, None, None, None, None, None, None, 0, 0,
+                                   part.data_ptr(), T, CA, S, _st()))
+    ps = part.sum(0)
+    s_, t_, mu, rstd, var = DT._bn_coeffs(ps[0, :S], ps[1, :S], T, gam.cuda(), bet.cuda())
+    assert _rel(mu.cpu(), y1.detach().mean(0)) <= 1e-4 and _rel(var.cpu(), y1.detach().var(0, unbiased=False)) <= 1e-4
+    part = torch.empty(nblk, 4, 16, device="cuda")
+    check(L.srk_spatial_gate_train(1, xd.data_ptr(), CA, W0d.data_ptr(), b0d.data_ptr(), s_.data_ptr(), t_.data_ptr(), w3d.data_ptr(), dsd.data_ptr(),
+                                   None, None, None, None, 0, 0, part.data_ptr(), T, CA, S, _st()))
+    ps = part.sum(0)
+    cA, cB, cC, dgam, dbet = (v.contiguous() for v in DT._bn_backward_coeffs(ps[0, :S], ps[1, :S], T, s_, mu, rstd))
+    assert _rel(dgam.cpu(), gr.grad) <= 1e-3 and _rel(dbet.cpu(), br.grad) <= 1e-3 and _rel(ps[2, :S].cpu(), w3r.grad) <= 1e-3
+    assert abs(float(ps[3, 0]) - float(dsm.sum())) <= 1e-3
+    dx = torch.zeros(T, CA, dtype=torch.bfloat16, device="cuda")
+    part = torch.empty(nblk, 16, CA + 1, device="cuda")
+    check(L.srk_spatial_gate_train(2, xd.data_ptr(), CA, W0d.data_ptr(), b0d.data_ptr(), s_.data_ptr(), t_.data_ptr(), w3d.data_ptr(), dsd.data_ptr(),
+                                   cA.data_ptr(), cB.data_ptr(), cC.data_ptr(), dx.data_ptr(), CA, 0, part.data_ptr(), T, CA, S, _st()))
+    ps = part.view(nblk, -1).sum(0).cpu()
+    assert _rel(dx.cpu().float(), xf.grad) <= 1e-2
+    assert _rel(ps[:16 * CA].view(16, CA)[:S], W0r.grad) <= 2e-3
+    assert float(ps[16 * CA:16 * CA + S].abs().max()) <= 1e-3 * float(dsm.abs().sum())        # the bias in front of a BatchNorm gets no gradient
+
+
+def test_dat_channel_attention_train_path_vs_autograd():
+    """chan_gram + the d x d softmax of dat_train.py + chan_apply_mat, forward and backward, against autograd of the reference's
+    formulation (:497-505) on the same bf16 q / k / v."""
+    from tpu_superresolution_amd import dat_train as DT
+    check, L = _lib()
+    g = torch.Generator().manual_seed(3)
+    B, N, nH, dh = 2, 600, 4, 12
+    CA = nH * 32
+    qkv = torch.zeros(B * N, 3 * CA)
+    real = torch.randn(B * N, 3, nH, dh, generator=g)
+    qkv.view(B * N, 3, nH, 32)[..., :dh] = real
+    qkv = _bf(qkv)
+    temp = torch.rand(nH, 1, 1, generator=g) + 0.5
+    dout = _bf(torch.randn(B * N, CA, generator=g))
+    r = qkv.float().view(B, N, 3, nH, 32)[..., :dh].permute(2, 0, 3, 4, 1).clone().requires_grad_(True)       # [3][B][h][d][N]
+    tr = temp.clone().requires_grad_(True)
+    attn = ((F.normalize(r[0], dim=-1) @ F.normalize(r[1], dim=-1).transpose(-2, -1)) * tr).softmax(-1)
+    out = (attn @ r[2]).permute(0, 3, 1, 2)                                                                    # [B][N][h][d]
+    out.backward(dout.float().view(B, N, nH, 32)[..., :dh])
+    qd = qkv.cuda()
+    part = torch.empty(int(L.srk_chan_gram_floats(B, N, nH)), device="cuda")
+    check(L.srk_chan_gram(qd.data_ptr(), 3 * CA, qd.data_ptr() + CA * 2, 3 * CA, part.data_ptr(), B, N, nH, _st()))
+    gg = part.view(B, nH, -1, 1088).sum(2)
+    G, sq, sk = gg[..., :1024].reshape(B, nH, 32, 32), gg[..., 1024:1056], gg[..., 1056:]
+    A = DT._channel_attention_matrix(G, sq, sk, temp.cuda(), dh).contiguous()
+    assert float((A[..., :dh, :dh].cpu() - attn.detach()).abs().max()) <= 1e-5
+    att = torch.zeros(B * N, CA, dtype=torch.bfloat16, device="cuda")
+    check(L.srk_chan_apply_mat(A.data_ptr(), qd.data_ptr() + 2 * CA * 2, 3 * CA, None, None, 0, att.data_ptr(), CA, B, N, nH, 0, _st()))
+    got = att.cpu().float().view(B, N, nH, 32)
+    assert _rel(got[..., :dh], out.detach()) <= 5e-3 and float(got[..., dh:].abs().max()) == 0.0
+    dod = dout.cuda()
+    check(L.srk_chan_gram(dod.data_ptr(), CA, qd.data_ptr() + 2 * CA * 2, 3 * CA, part.data_ptr(), B, N, nH, _st()))
+    dA = part.view(B, nH, -1, 1088).sum(2)[..., :1024].reshape(B, nH, 32, 32)
+    dqkv = torch.zeros(B * N, 3 * CA, dtype=torch.bfloat16, device="cuda")
+    At = A.transpose(-1, -2).contiguous()
+    check(L.srk_chan_apply_mat(At.data_ptr(), dod.data_ptr(), CA, None, None, 0, dqkv.data_ptr() + 2 * CA * 2, 3 * CA, B, N, nH, 0, _st()))
+    Gm, sqm, skm, tm = (t.detach().requires_grad_(True) for t in (G, sq, sk, temp.cuda()))
+    dG, dsq, dsk, dtemp = torch.autograd.grad(DT._channel_attention_matrix(Gm, sqm, skm, tm, dh), [Gm, sqm, skm, tm], dA)
+    dG, dGt, dsq2, dsk2 = dG.contiguous(), dG.transpose(-1, -2).contiguous(), (2 * dsq).contiguous(), (2 * dsk).contiguous()
+    check(L.srk_chan_apply_mat(dG.data_ptr(), qd.data_ptr() + CA * 2, 3 * CA, dsq2.data_ptr(), qd.data_ptr(), 3 * CA, dqkv.data_ptr(), 3 * CA, B, N, nH, 0,
+                               _st()))
+    check(L.srk_chan_apply_mat(dGt.data_ptr(), qd.data_ptr(), 3 * CA, dsk2.data_ptr(), qd.data_ptr() + CA * 2, 3 * CA, dqkv.data_ptr() + CA * 2, 3 * CA, B,
+                               N, nH, 0, _st()))
+    got = dqkv.cpu().float().view(B, N, 3, nH, 32)[..., :dh].permute(2, 0, 3, 4, 1)
+    for w_, nm in enumerate("qkv"):
+        assert _rel(got[w_], r.grad[w_]) <= 2e-2, nm
+    assert _rel(dtemp.cpu(), tr.grad) <= 1e-3
+
+
+@pytest.mark.parametrize("wh,ww,shift,H,W", [(8, 32, True, 32, 64), (32, 8, False, 24, 40), (8, 16, True, 24, 40), (16, 8, True, 32, 32)])
+def test_dat_rect_window_attention_backward_vs_autograd(wh, ww, shift, H, W):
+    """csrc/attn_rect_bwd.hip against autograd of the oracle's window attention on the padded frame (zero-padded q / k / v, cyclic shift,
+    arithmetic mask, dense bias): d q / d k / d v per token and the dense bias gradient."""
+    check, L = _lib()
+    g = torch.Generator().manual_seed(wh * 100 + ww + H)
+    B, nH, dh = 2, 2, 12
+    CA = 2 * nH * 32                    # the launch covers one branch's half of the heads (as Adaptive_Spatial_Attention does)
+    N = wh * ww
+    big = max(wh, ww)
+    Hp, Wp = (H + big - 1) // big * big, (W + big - 1) // big * big
+    sy, sx = (wh // 2, ww // 2) if shift else (0, 0)
+    scale = dh ** -0.5
+    T = B * H * W
+    qkv = torch.zeros(T, 3, 2 * nH, 32)
+    qkv[..., :nH, :dh] = torch.randn(T, 3, nH, dh, generator=g)
+    qkv = _bf(qkv.reshape(T, 3 * CA))
+    bias = torch.randn(nH, N, N, generator=g) * 0.5
+    dout = torch.zeros(T, 2 * nH, 32)
+    dout[:, :nH, :dh] = torch.randn(T, nH, dh, generator=g)
+    dout = _bf(dout.reshape(T, CA))
+    # reference: the oracle's formulation with autograd
+    x = qkv.float().view(B, H, W, 3, 2 * nH, 32)[..., :nH, :dh].clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    xp = F.pad(x, (0, 0, 0, 0, 0, 0, 0, Wp - W, 0, Hp - H)).reshape(B, Hp * Wp, 3, nH, dh)
+    idx = torch.from_numpy(DO.rect_window_token_index(Hp, Wp, wh, ww, sy, sx))
+    nW = idx.shape[0]
+    win = xp[:, idx.reshape(-1)].reshape(B * nW, N, 3, nH, dh).permute(2, 0, 3, 1, 4)
+    attn = (win[0] * scale) @ win[1].transpose(-2, -1) + br[None]
+    if shift:
+        attn = (attn.reshape(B, nW, nH, N, N) + torch.from_numpy(DO.rect_shift_mask(Hp, Wp, wh, ww, sy, sx))[None, :, None]).reshape(-1, nH, N, N)
+    o = (attn.softmax(-1) @ win[2]).transpose(1, 2).reshape(B, nW * N, nH, dh)
+    merged = torch.zeros(B, Hp * Wp, nH, dh).index_copy(1, idx.reshape(-1), o).reshape(B, Hp, Wp, nH, dh)[:, :H, :W]
+    merged.backward(dout.float().view(B, H, W, 2 * nH, 32)[..., :nH, :dh])
+    qd, dod, bd = qkv.cuda(), dout.cuda(), bias.cuda()
+    dqkv = torch.zeros(T, 3 * CA, dtype=torch.bfloat16, device="cuda")
+    dbias = torch.zeros(nH, N, N, device="cuda")
+    check(L.srk_win_attention_bwd_padded(qd.data_ptr(), 3 * CA, CA, bd.data_ptr(), dod.data_ptr(), CA, dqkv.data_ptr(), dbias.data_ptr(), B, H, W, Hp, Wp,
+                                         wh, ww, sy, sx, nH, scale, _st()))
+    got = dqkv.cpu().float().view(B, H, W, 3, 2 * nH, 32)
+    for w_, nm in enumerate("qkv"):
+        assert _rel(got[..., w_, :nH, :dh], x.grad[..., w_, :, :]) <= 2e-2, nm
+    assert float(got[..., nH:, :].abs().max()) == 0.0                 # the other branch's heads are not this launch's
+    assert _rel(dbias.cpu(), br.grad) <= 1e-2
+
+
+def _train_model(cfg, sd, drop_path_rate=0.0):
+    import tpu_superresolution_amd as T
+    m = T.DAT(**cfg.kwargs(), drop_path_rate=drop_path_rate)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().train()
+
+
+def _check_grads(m, want: dict, tol=0.1, floor=2e-3):
+    """per-tensor relative error <= tol, measured against max(|reference gradient|, floor * the largest gradient norm of the model): the
+    gradients that are mathematically zero (a bias in front of a BatchNorm, a softmax-invariant shift) are noise in both."""
+    biggest = max(float(v.norm()) for v in want.values())
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        assert p.grad is not None, n
+        w = want[n]
+        e = float((p.grad.cpu().float() - w).norm()) / max(float(w.norm()), floor * biggest)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"worst gradient error {worst[1]:.3e} at {worst[0]}")
+    assert worst[1] <= tol, worst
+
+
+@pytest.mark.parametrize("tag", ["32x32", "24x40"])
+def test_dat_train_step_vs_reference_golden(tag):
+    """G14c: one training step of the reference's DAT in .train() (BatchNorm batch statistics, drop_path 0): loss, output, every
+    parameter's gradient and the BatchNorm buffers after the step."""
+    from test_oracle_golden import DAT_TINY
+    g = load_golden("g14c_dat_train")
+    cfg = DO.DATConfig(**DAT_TINY)
+    sd = DO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    m = _train_model(cfg, sd)
+    x, t = torch.from_numpy(g[f"{tag}.x"]).cuda(), torch.from_numpy(g[f"{tag}.t"]).cuda()
+    y = m(x)
+    loss = F.l1_loss(y, t)
+    loss.backward()
+    yr = torch.from_numpy(g[f"{tag}.y"])
+    assert float((y.detach().cpu() - yr).abs().max()) <= 2e-2 * float(yr.abs().max())
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) <= 5e-3 * float(g[f"{tag}.loss"])
+    _check_grads(m, {n: torch.from_numpy(g[f"{tag}.grad.{n}"]) for n, _ in m.named_parameters()})
+    for n, b in m.named_buffers():
+        if n.endswith(("running_mean", "running_var")):
+            r = torch.from_numpy(g[f"{tag}.buf.{n}"])
+            assert float((b.cpu() - r).abs().max()) <= 2e-2 * max(float(r.abs().max()), 1e-2), n
+        elif n.endswith("num_batches_tracked"):
+            assert int(b) == int(g[f"{tag}.buf.{n}"])
+    # the eval forward afterwards folds the UPDATED running statistics
+    m.eval()
+    with torch.no_grad():
+        ye = m(x)
+    sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = DO.dat_forward(sd2, cfg, x.cpu())
+    assert float((ye.cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
+def test_dat_train_step_with_drop_path_vs_oracle():
+    """DropPath factors drawn by DAT.forward (seeded) and handed to the oracle: loss and gradients of the same step."""
+    from test_oracle_golden import DAT_TINY_816
+    cfg = DO.DATConfig(**DAT_TINY_816)
+    sd = DO.random_state_dict(cfg, seed=21, scale=2.0)
+    m = _train_model(cfg, sd, drop_path_rate=0.3)
+    gen = torch.Generator().manual_seed(4)
+    x, t = torch.rand(3, 3, 24, 40, generator=gen), torch.rand(3, 3, 48, 80, generator=gen)
+    torch.manual_seed(11)
+    torch.cuda.manual_seed(11)
+    y = m(x.cuda())
+    F.l1_loss(y, t.cuda()).backward()
+    torch.manual_seed(11)
+    torch.cuda.manual_seed(11)
+    probs = [blk.drop_path_prob for layer in m.layers for blk in layer.blocks]
+    keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device="cuda").view(-1, 1, 1)
+    drop = ((torch.rand(len(probs), 2, 3, device="cuda") < keep).float() / keep).cpu()
+    assert float(drop.min()) == 0.0                                   # some branch is dropped for some sample
+    loss, yo, grads, _ = DO.loss_and_grads(sd, cfg, x, t, drop)
+    assert float((y.detach().cpu() - yo).abs().max()) <= 2e-2 * float(yo.abs().max())
+    _check_grads(m, grads)

@@ -387,6 +387,32 @@ def test_g14b_dat_padded_frames_and_128_token_windows(tag):
             assert (got - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), (tag, name)
 
 
+@pytest.mark.parametrize("tag", ["32x32", "24x40"])
+def test_g14c_dat_training_step(tag):
+    """The training oracle (train_mode: BatchNorm batch statistics + running-statistic updates, autograd for the gradients) against one
+    training step of the reference's DAT in .train(): loss, output, all 264 parameter gradients, the 45 BatchNorm buffers."""
+    from oracle import dat_oracle as DO
+    g = load_golden("g14c_dat_train")
+    cfg = DO.DATConfig(**DAT_TINY)
+    sd = DO.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g["weight_sha1"])
+    x, t = torch.from_numpy(g[f"{tag}.x"]), torch.from_numpy(g[f"{tag}.t"])
+    loss, y, grads, rec = DO.loss_and_grads(sd, cfg, x, t)
+    assert abs(loss - float(g[f"{tag}.loss"])) <= 1e-6
+    assert float((y - torch.from_numpy(g[f"{tag}.y"])).abs().max()) <= 2e-5
+    biggest = max(float(torch.from_numpy(g[f"{tag}.grad.{k}"]).norm()) for k in grads)
+    for k, v in grads.items():          # gradients that are mathematically zero (a bias in front of a BatchNorm) are 1e-9 noise in both
+        r = torch.from_numpy(g[f"{tag}.grad.{k}"])
+        assert float((v - r).norm()) <= 1e-3 * float(r.norm()) + 1e-6 * biggest, k
+    assert len(rec) == 45
+    for k, v in rec.items():
+        r = torch.from_numpy(g[f"{tag}.buf.{k}"])
+        assert torch.allclose(v.to(r.dtype), r, rtol=1e-5, atol=1e-6), k
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        DO.loss_and_grads(sd, cfg, x[:1], t[:1])
+
+
 # ---- G15: SwinIR with ape=True ------------------------------------------------------------------------------------------------------
 TINY_APE = dict(img_size=16, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8, mlp_ratio=2, img_range=1.0,
                 resi_connection="1conv", upscale=2, upsampler="pixelshuffle", ape=True)

@@ -15,9 +15,11 @@ DAT x4 configuration), same ``forward(x[B,C,H,W]) -> [B,C,H*s,W*s]``.  As for HA
     channel / spatial interaction + gating (:315-327, :430-436) srk_channel_gate_act, srk_spatial_gate, srk_dual_gate_combine
     SGFN (:57-90)                                             fc1 + GELU GEMM, srk_rowln_bf16, srk_dwconv3x3 with the gating multiply, fc2 + residual
 
-Scope this round: INFERENCE in eval mode (BatchNorm uses running statistics).
-split_size with 256 tokens per window (8x32, 16x16, ...), H and W multiples of the larger split size (the reference zero-pads
-q/k/v otherwise -- not built), head_dim <= 32, embed_dim <= 256, resi_connection '1conv', both upsamplers.  No CPU fallback.
+Scope: inference (eval mode, BatchNorm's running statistics folded at pack time) AND training (train mode:
+batch statistics + running-statistic updates, DropPath as data, hand-written backward -- ``dat_train.py``; a grad-enabled forward
+in eval mode is inference and builds no graph).  split_size with 256 or 128 tokens per window (8x32, 16x16, 8x16, ...); any H, W
+(q / k / v zero-padded to a multiple of the larger split as the reference does); head_dim <= 32, embed_dim <= 256,
+resi_connection '1conv', both upsamplers.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -172,7 +174,8 @@ class DATB(nn.Module):
                                                    qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop, rg_idx=rg_idx, b_idx=b_idx)
         else:
             self.attn = Adaptive_Channel_Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = nn.Identity()        # the reference's DropPath holds no state; the factors are drawn in DAT.forward and passed as data
+        self.drop_path_prob = float(drop_path)
         self.ffn = SGFN(in_features=dim, hidden_features=int(dim * expansion_factor), out_features=dim, act_layer=act_layer)
         self.norm2 = norm_layer(dim)
     forward = _holder_forward
@@ -376,13 +379,24 @@ class DAT(nn.Module):
         why = self._unsupported_reason()
         if why:
             raise SrkUnsupported(f"the MI355X HIP path does not cover {why}; no fallback path exists in this package")
-        if self.training:
-            raise SrkUnsupported("DAT on the HIP path runs in eval mode only (BatchNorm running statistics; training is not built): "
-                                 "call model.eval()")
         p0 = next(self.parameters())
         if p0.device != x.device:
             raise RuntimeError(f"input is on {x.device} but the model is on {p0.device}")
         _lib.claim_device(x.device.index if x.device.index is not None else torch.cuda.current_device())
+        if self.training:
+            # train mode: BatchNorm normalises with the batch's statistics and moves its running estimates, DropPath factors are drawn
+            # here (dat_arch.py:562-563) and passed to the kernels as data; with grad enabled the whole model is ONE autograd node whose
+            # backward is dat_train.dat_backward
+            from .dat_train import DATFunction, dat_forward_train, pack_train
+            drop = None
+            probs = [blk.drop_path_prob for layer in self.layers for blk in layer.blocks]
+            if any(pr > 0 for pr in probs):
+                keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
+                drop = (torch.rand(len(probs), 2, x.shape[0], device=x.device) < keep).float() / keep
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                return DATFunction.apply(self, x, drop, *[p for _, p in self.named_parameters()])
+            with torch.no_grad(), torch.cuda.device(x.device):
+                return dat_forward_train(self, x.contiguous().float(), self._pack(x.device), pack_train(self, x.device), drop)[0]
         with torch.no_grad(), torch.cuda.device(x.device):
             return _dat_forward(self, x.contiguous().float(), self._pack(x.device))
 

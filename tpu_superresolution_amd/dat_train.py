@@ -264,8 +264,9 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
             _bn_update(si[1], si_mu, si_var, T)
             tgate = torch.empty(T, **f32)
             w3 = si[3].weight.float().reshape(S2).contiguous()
-            check(L.srk_spatial_gate(tok_src.data_ptr(), CA, (w0raw * si_s[:, None]).contiguous().data_ptr(), (b0raw * si_s + si_t).contiguous().data_ptr(),
-                                     w3.data_ptr(), float(si[3].bias), S2, tgate.data_ptr(), T, CA, st))
+            w0f, b0f = (w0raw * si_s[:, None]).contiguous(), (b0raw * si_s + si_t).contiguous()          # BatchNorm folded for the forward kernel
+            check(L.srk_spatial_gate(tok_src.data_ptr(), CA, w0f.data_ptr(), b0f.data_ptr(), w3.data_ptr(), float(si[3].bias), S2, tgate.data_ptr(), T,
+                                     CA, st))
             comb = torch.empty(T, CA, **b16)            # tok_src * cgate + gate_src * tgate  (:430-436 / :518-524)
             check(L.srk_dual_gate_combine(tok_src.data_ptr(), gate_src.data_ptr(), cgate.data_ptr(), tgate.data_ptr(), comb.data_ptr(), T, HW, CA, 0, st))
             x1 = torch.empty(T, CP, **f32)
@@ -536,15 +537,15 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             check(L.srk_spatial_gate_train(1, tok_src.data_ptr(), CA, w0raw.data_ptr(), b0raw.data_ptr(), si_s.data_ptr(), si_t.data_ptr(), w3.data_ptr(),
                                            dsmap.data_ptr(), None, None, None, None, 0, 0, part.data_ptr(), T, CA, S2, st))
             ps = part.sum(0)
-            cA, cB, cC, dgam, dbet = _bn_backward_coeffs(ps[0, :S2], ps[1, :S2], T, si_s, bk["si_mu"], bk["si_rstd"])
+            cA, cB, cC, dgam, dbet = (t.contiguous() for t in _bn_backward_coeffs(ps[0, :S2], ps[1, :S2], T, si_s, bk["si_mu"], bk["si_rstd"]))
             put(si[1].weight, dgam)
             put(si[1].bias, dbet)
             put(si[3].weight, ps[2, :S2])
             put(si[3].bias, ps[3, :1])
             part = torch.empty(nblk, 16, CA + 1, **f32)
             check(L.srk_spatial_gate_train(2, tok_src.data_ptr(), CA, w0raw.data_ptr(), b0raw.data_ptr(), si_s.data_ptr(), si_t.data_ptr(), w3.data_ptr(),
-                                           dsmap.data_ptr(), cA.contiguous().data_ptr(), cB.contiguous().data_ptr(), cC.contiguous().data_ptr(),
-                                           d_tok_src.data_ptr(), CA, 1, part.data_ptr(), T, CA, S2, st))
+                                           dsmap.data_ptr(), cA.data_ptr(), cB.data_ptr(), cC.data_ptr(), d_tok_src.data_ptr(), CA, 1, part.data_ptr(), T,
+                                           CA, S2, st))
             ps = part.view(nblk, -1).sum(0)
             put(si[0].weight, ps[:16 * CA].view(16, CA)[:S2][:, hm])
             put(si[0].bias, ps[16 * CA:16 * CA + S2])
@@ -555,12 +556,12 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             check(L.srk_dgelu_affine_bf16(d_conv.data_ptr(), CA, c_pre.data_ptr(), CA, bk["dw_s"].data_ptr(), bk["dw_t"].data_ptr(), dz.data_ptr(), CA, T,
                                           CA // 8, st))
             S1, S2_ = token_sums(dz.data_ptr(), CA, c_pre.data_ptr(), CA, CA // 8)
-            cA, cB, cC, dgam, dbet = _bn_backward_coeffs(S1, S2_, T, bk["dw_s"], bk["dw_mu"], bk["dw_rstd"])
+            cA, cB, cC, dgam, dbet = (t.contiguous() for t in _bn_backward_coeffs(S1, S2_, T, bk["dw_s"], bk["dw_mu"], bk["dw_rstd"]))
             put(at.dwconv[1].weight, dgam[hm])
             put(at.dwconv[1].bias, dbet[hm])
             dcpre = d_conv                                          # (re-used buffer)
-            check(L.srk_lincomb2_bf16(dz.data_ptr(), CA, c_pre.data_ptr(), CA, cA.contiguous().data_ptr(), cB.contiguous().data_ptr(),
-                                      cC.contiguous().data_ptr(), dcpre.data_ptr(), CA, T, CA // 8, 0, 0, st))
+            check(L.srk_lincomb2_bf16(dz.data_ptr(), CA, c_pre.data_ptr(), CA, cA.data_ptr(), cB.data_ptr(), cC.data_ptr(), dcpre.data_ptr(), CA, T,
+                                      CA // 8, 0, 0, st))
             dwconv_grads(dcpre.data_ptr(), CA, v_ptr, 3 * CA, CA, at.dwconv[0], hm)
             dv_conv = dz                                            # (re-used buffer)
             check(L.srk_dwconv3x3(dcpre.data_ptr(), CA, PT[pre + "dw_wf"].data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, 0, dv_conv.data_ptr(), CA,
@@ -595,10 +596,9 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                     dG, dsq, dsk, dtemp = torch.autograd.grad(A, [Gm, sq, sk, at.temperature], dA)
                 put(at.temperature, dtemp)
                 q_ptr, k_ptr = qkv.data_ptr(), qkv.data_ptr() + CA * 2
-                check(L.srk_chan_apply_mat(dG.contiguous().data_ptr(), k_ptr, 3 * CA, (2.0 * dsq).contiguous().data_ptr(), q_ptr, 3 * CA, dqkv.data_ptr(),
-                                           3 * CA, B, HW, nH, 0, st))
-                check(L.srk_chan_apply_mat(dG.transpose(-1, -2).contiguous().data_ptr(), q_ptr, 3 * CA, (2.0 * dsk).contiguous().data_ptr(), k_ptr, 3 * CA,
-                                           dqkv.data_ptr() + CA * 2, 3 * CA, B, HW, nH, 0, st))
+                dG, dGt, dsq2, dsk2 = dG.contiguous(), dG.transpose(-1, -2).contiguous(), (2.0 * dsq).contiguous(), (2.0 * dsk).contiguous()
+                check(L.srk_chan_apply_mat(dG.data_ptr(), k_ptr, 3 * CA, dsq2.data_ptr(), q_ptr, 3 * CA, dqkv.data_ptr(), 3 * CA, B, HW, nH, 0, st))
+                check(L.srk_chan_apply_mat(dGt.data_ptr(), q_ptr, 3 * CA, dsk2.data_ptr(), k_ptr, 3 * CA, dqkv.data_ptr() + CA * 2, 3 * CA, B, HW, nH, 0, st))
             check(L.srk_lincomb2_bf16(dv_conv.data_ptr(), CA, None, 0, None, None, None, dqkv.data_ptr() + 2 * CA * 2, 3 * CA, T, CA // 8, 0, 1, st))
             lin_wgrad(dqkv, bk["xn1"], at.qkv, row_map=qkv_rows)
             dxn1 = torch.empty(T, CP, **b16)
