@@ -279,17 +279,20 @@ def bench_inference(args):
 
 
 def bench_hat_train(args):
-    """BASELINE cfg4 as a TRAIN step: HAT-SRx4, 64x64 LR, bs 16 per GPU: forward (activations kept) + L1 +
-    backward (hat_train.hat_backward through the C ABI) + clip 1.0 + AdamW.  The optimizer is torch's (foreach) AdamW on the
-    module's own parameters -- the fused flat-buffer optimizer belongs to the SwinIR engine.  N > 1: per-segment gradient
-    all-reduce on a side stream (distributed.ListGradSynchronizer), overlapped with the backward of the next segment."""
+    """BASELINE cfg4 / cfg5 as a TRAIN step: HAT-SRx4 or DAT x4, 64x64 LR, bs 16 per GPU: forward
+    (activations kept; DAT: BatchNorm with batch statistics) + L1 + backward (hat_train.hat_backward / dat_train.dat_backward through
+    the C ABI) + clip 1.0 + AdamW.  The optimizer is torch's (foreach) AdamW on the module's own parameters -- the fused flat-buffer
+    optimizer belongs to the SwinIR engine.  N > 1: per-segment gradient all-reduce on a side stream
+    (distributed.ListGradSynchronizer), overlapped with the backward of the next segment; BatchNorm statistics stay per rank (as
+    nn.BatchNorm2d under DDP without SyncBatchNorm)."""
     import torch.distributed as dist
     from tpu_superresolution_amd.distributed import ListGradSynchronizer, init_from_env
     from tpu_superresolution_amd.training import l1_loss_checked
     rank, world, local = init_from_env("nccl") if args.gpus > 1 else (0, 1, 0)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    model = build_infer_model("cfg4", device).train()
+    cfg_name = args.config
+    model = build_infer_model(cfg_name, device).train()
     if world > 1:
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
@@ -336,16 +339,17 @@ def bench_hat_train(args):
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * bs * HR_PX_PER_SAMPLE * args.steps / elapsed
-        flop_step = 3.0 * bs * INFER["cfg4"]["flop_per_image"]            # fwd + bwd ~ 3 x the reference's forward FLOPs
-        out = {"metric": "HR pixels/sec, HAT x4 train step, 64x64 LR, bs=16/GPU", "value": value, "unit": "HR pixels/s", "n_gpus": world,
+        flop_step = 3.0 * bs * INFER[cfg_name]["flop_per_image"]            # fwd + bwd ~ 3 x the reference's forward FLOPs
+        what = {"cfg4": ("HAT", "BASELINE cfg4 as a train step: HAT-SRx4 (dim 180, 6x6 HAB + 6 OCAB, window 16, overlap 0.5, CAB) fwd + L1 + "),
+                "cfg5": ("DAT", "BASELINE cfg5 as a train step: DAT x4 (dim 180, 6x6 DATB, split 8x32, BatchNorm with batch statistics) fwd + L1 + ")}[cfg_name]
+        out = {"metric": f"HR pixels/sec, {what[0]} x4 train step, 64x64 LR, bs=16/GPU", "value": value, "unit": "HR pixels/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE cfg4 as a train step: HAT-SRx4 (dim 180, 6x6 HAB + 6 OCAB, window 16, overlap 0.5, CAB) fwd + L1 + "
-                                      "bwd + clip 1.0 + AdamW (torch foreach), 64x64 LR -> 256x256 HR, random-init weights, drop_path 0.1",
+               "config": {"workload": what[1] + "bwd + clip 1.0 + AdamW (torch foreach), 64x64 LR -> 256x256 HR, random-init weights, drop_path 0.1",
                           "batch_per_gpu": bs, "global_batch": bs * world, "parallelism": f"dp{world}", "per_gpu_value": value / world,
                           "ms_per_step_median": step_ms[len(step_ms) // 2], "step_tflops_per_gpu": flop_step / (ms_per_step * 1e-3) / 1e12,
                           "final_loss": float(loss)},
-               "roofline": {"bound": "mfma", "kernel": "whole HAT train step", "achieved": flop_step / (ms_per_step * 1e-3) / 1e12,
+               "roofline": {"bound": "mfma", "kernel": f"whole {what[0]} train step", "achieved": flop_step / (ms_per_step * 1e-3) / 1e12,
                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_step / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                             "traffic": None}}
         if world > 1:
@@ -403,7 +407,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
-    ap.add_argument("--train", action="store_true", help="cfg4: time a HAT TRAIN step (fwd + L1 + bwd + clip + AdamW) instead of inference")
+    ap.add_argument("--train", action="store_true", help="cfg4 / cfg5: time a HAT / DAT TRAIN step (fwd + L1 + bwd + clip + AdamW) instead of inference")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="developer A/B: srk_set_option(NAME, VALUE) before the model is built (repeatable)")
     args = ap.parse_args()
@@ -418,8 +422,8 @@ def main():
         name, _, value = item.partition("=")
         _l.check(_l.lib().srk_set_option(name.encode(), int(value)))
     if args.train:
-        if args.config != "cfg4":
-            raise SystemExit("--train selects the HAT train step: use it with --config cfg4 (cfg3, the default, is a train step already)")
+        if args.config not in ("cfg4", "cfg5"):
+            raise SystemExit("--train selects the HAT / DAT train step: use it with --config cfg4 or cfg5 (cfg3, the default, is a train step already)")
         if args.steps == 10:
             args.steps = 5
         return bench_hat_train(args)

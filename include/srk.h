@@ -358,10 +358,12 @@ int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float*
  * the DynamicPosBias MLP :93-130) are evaluated by the caller on the reductions these return (tpu_superresolution_amd/dat_train.py).
  * All bf16 operands are row-major [rows][ld] with 8-element (16-byte) aligned rows; C8 = channels / 8. */
 /* backward of srk_win_attention_fwd_padded with a dense bias: d_qkv (q | k | v slices of the heads of this launch) and d_bias
- * [heads][N][N] ACCUMULATED (zero it first) over the windows */
+ * [heads][N][N] ACCUMULATED (zero it first) over the windows.  scratch: null (d_bias by float atomics) or
+ * srk_win_attention_bwd_padded_scratch bytes (per-window dS tiles + a reduction kernel: the fast path) */
+size_t srk_win_attention_bwd_padded_scratch(int B, int Hp, int Wp, int wh, int ww, int num_heads);
 int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, const uint16_t* d_out, int ldo, uint16_t* d_qkv,
-                                 float* d_bias, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x, int num_heads,
-                                 float scale, srk_stream_t stream);
+                                 float* d_bias, void* scratch, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x,
+                                 int num_heads, float scale, srk_stream_t stream);
 /* partial [samples][chunks][2][8 C8]: per 256-row chunk of a sample, sum_t p[t][c] and sum_t p[t][c] q[t][c] (fixed order; the caller
  * sums the chunks).  BatchNorm batch statistics (q = p), its backward sums (p = dz, q = x), the pooled mean (samples = B). */
 int64_t srk_chan_stats_chunks(int64_t rows_per_sample);
@@ -379,7 +381,8 @@ int srk_lincomb2_bf16(const uint16_t* p, int ldp, const uint16_t* q, int ldq, co
 /* d a = dy * b, d b = dy * a  (SpatialGate's x1 * x2, dat_arch.py:54) */
 int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* da, int ldda, uint16_t* db,
                      int lddb, int64_t rows, int C8, srk_stream_t stream);
-/* depth-wise 3x3 (pad 1): partial [B][ceil(H / 8)][10][8 C8]; rows 0..8 the taps' weight gradient, row 9 the bias gradient */
+/* depth-wise 3x3 (pad 1): partial [B][srk_dwconv3x3_wgrad_chunks(H)][10][8 C8]; rows 0..8 the taps' weight gradient, row 9 the bias gradient */
+int srk_dwconv3x3_wgrad_chunks(int H);
 int srk_dwconv3x3_wgrad(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, float* partial, int B, int H, int W, int C8,
                         srk_stream_t stream);
 /* backward of srk_dual_gate_combine, out = a_chan * cgate[b][c] + a_tok * tgate[t]:  d_chan = d * cgate, d_tok = d * tgate,
@@ -396,7 +399,7 @@ int srk_spatial_gate_train(int what, const uint16_t* x, int ldx, const float* W0
                            const float* w3, const float* dsmap, const float* cA, const float* cB, const float* cC, uint16_t* dx, int lddx,
                            int accumulate, float* partial, int64_t rows, int C, int S, srk_stream_t stream);
 /* LayerNorm (eps 1e-5) backward on bf16 rows (SpatialGate.norm): dx bf16 (columns C..CP_out zero); partial [blocks][2][C] with the
- * workgroups' d gamma / d beta sums, blocks = srk_rowln_bwd_blocks(rows) */
+ * workgroups' d gamma / d beta sums, blocks = srk_rowln_bwd_blocks(rows); CP_out <= 512 */
 int64_t srk_rowln_bwd_blocks(int64_t rows);
 int srk_rowln_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* gamma, uint16_t* dx, int lddx, float* partial,
                        int64_t rows, int C, int CP_out, srk_stream_t stream);

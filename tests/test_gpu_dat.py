@@ -236,7 +236,7 @@ def test_dat_train_token_kernels_vs_torch():
     bs = torch.zeros(C, requires_grad=True)
     xi = pf.reshape(B, H, W, C).permute(0, 3, 1, 2)
     F.conv2d(xi, wt, bs, padding=1, groups=C).backward(qf.reshape(B, H, W, C).permute(0, 3, 1, 2))
-    part = torch.empty(B, (H + 7) // 8, 10, C, device="cuda")
+    part = torch.empty(B, int(L.srk_dwconv3x3_wgrad_chunks(H)), 10, C, device="cuda")
     check(L.srk_dwconv3x3_wgrad(qd.data_ptr() + 16, ld, pd.data_ptr() + 16, ld, part.data_ptr(), B, H, W, C // 8, _st()))
     got = part.sum((0, 1)).cpu()
     assert _rel(got[:9].t().reshape(C, 1, 3, 3), wt.grad) <= 1e-5 and _rel(got[9], bs.grad) <= 1e-5
@@ -403,9 +403,14 @@ def test_dat_rect_window_attention_backward_vs_autograd(wh, ww, shift, H, W):
     merged.backward(dout.float().view(B, H, W, 2 * nH, 32)[..., :nH, :dh])
     qd, dod, bd = qkv.cuda(), dout.cuda(), bias.cuda()
     dqkv = torch.zeros(T, 3 * CA, dtype=torch.bfloat16, device="cuda")
-    dbias = torch.zeros(nH, N, N, device="cuda")
-    check(L.srk_win_attention_bwd_padded(qd.data_ptr(), 3 * CA, CA, bd.data_ptr(), dod.data_ptr(), CA, dqkv.data_ptr(), dbias.data_ptr(), B, H, W, Hp, Wp,
-                                         wh, ww, sy, sx, nH, scale, _st()))
+    dbias, dbias2 = torch.zeros(nH, N, N, device="cuda"), torch.zeros(nH, N, N, device="cuda")
+    scr = torch.empty(int(L.srk_win_attention_bwd_padded_scratch(B, Hp, Wp, wh, ww, nH)), dtype=torch.uint8, device="cuda")
+    check(L.srk_win_attention_bwd_padded(qd.data_ptr(), 3 * CA, CA, bd.data_ptr(), dod.data_ptr(), CA, dqkv.data_ptr(), dbias2.data_ptr(), None, B, H, W,
+                                         Hp, Wp, wh, ww, sy, sx, nH, scale, _st()))          # without scratch: float atomics
+    dqkv.zero_()
+    check(L.srk_win_attention_bwd_padded(qd.data_ptr(), 3 * CA, CA, bd.data_ptr(), dod.data_ptr(), CA, dqkv.data_ptr(), dbias.data_ptr(), scr.data_ptr(),
+                                         B, H, W, Hp, Wp, wh, ww, sy, sx, nH, scale, _st()))  # per-window tiles + reduction
+    assert _rel(dbias2.cpu(), dbias.cpu()) <= 1e-5
     got = dqkv.cpu().float().view(B, H, W, 3, 2 * nH, 32)
     for w_, nm in enumerate("qkv"):
         assert _rel(got[..., w_, :nH, :dh], x.grad[..., w_, :, :]) <= 2e-2, nm
@@ -486,5 +491,20 @@ def test_dat_train_step_with_drop_path_vs_oracle():
     drop = ((torch.rand(len(probs), 2, 3, device="cuda") < keep).float() / keep).cpu()
     assert float(drop.min()) == 0.0                                   # some branch is dropped for some sample
     loss, yo, grads, _ = DO.loss_and_grads(sd, cfg, x, t, drop)
+    assert float((y.detach().cpu() - yo).abs().max()) <= 2e-2 * float(yo.abs().max())
+    _check_grads(m, grads)
+
+
+def test_dat_train_step_pixelshuffledirect_vs_oracle():
+    """The light-weight head (UpsampleOneStep, dat_arch.py:846-848) in training: fp32 small-conv gradients through the un-shuffled image."""
+    from test_oracle_golden import DAT_TINY
+    cfg = DO.DATConfig(**dict(DAT_TINY, upsampler="pixelshuffledirect", depth=(2,), num_heads=(4,)))
+    sd = DO.random_state_dict(cfg, seed=23, scale=2.0)
+    m = _train_model(cfg, sd)
+    gen = torch.Generator().manual_seed(6)
+    x, t = torch.rand(2, 3, 32, 32, generator=gen), torch.rand(2, 3, 64, 64, generator=gen)
+    y = m(x.cuda())
+    F.l1_loss(y, t.cuda()).backward()
+    loss, yo, grads, _ = DO.loss_and_grads(sd, cfg, x, t)
     assert float((y.detach().cpu() - yo).abs().max()) <= 2e-2 * float(yo.abs().max())
     _check_grads(m, grads)

@@ -129,13 +129,15 @@ _SIGNATURES = {
     "srk_dual_gate_combine": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_channel_attention_workspace": (_sz, [_i, _i, _i]),
     "srk_channel_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "srk_win_attention_bwd_padded": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "srk_win_attention_bwd_padded_scratch": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "srk_win_attention_bwd_padded": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "srk_chan_stats_chunks": (_i64, [_i64]),
     "srk_chan_stats": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "srk_affine_act_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "srk_dgelu_affine_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     "srk_lincomb2_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "srk_mul_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    "srk_dwconv3x3_wgrad_chunks": (_i, [_i]),
     "srk_dwconv3x3_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "srk_dual_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srk_spatial_gate_train": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _vp]),

@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int ST_ROWS = 256;     // tokens per workgroup of the reduction passes
+constexpr int DW_ROWS = 2;       // image rows per workgroup of the depth-wise weight gradient (B * H / 2 workgroups fill the chip at 64 x 64)
 
 inline int grid_cap(long long n, int block = 256, int cap = 16384) {
   long long g = (n + block - 1) / block;
@@ -156,11 +157,11 @@ __global__ __launch_bounds__(256) void mul_bwd_kernel(const bf16_t* __restrict__
 }
 
 // depth-wise 3x3 (pad 1) weight gradient: partial[chunk][tap][c] = sum over the chunk's pixels of dy[pix][c] x[pix + off(tap)][c],
-// partial[chunk][9][c] = sum dy.  One workgroup per (sample, 8 image rows); thread = 8-channel piece x pixel lane.
+// partial[chunk][9][c] = sum dy.  One workgroup per (sample, DW_ROWS image rows); thread = 8-channel piece x pixel lane.
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                               float* __restrict__ partial, int H, int W, int C8) {
   __shared__ float red[8][10][8 * 32 / 8 + 1];      // [lane][tap][channel of the piece group]  (re-used per piece group)
-  const int b = blockIdx.y, y0 = blockIdx.x * 8;
+  const int b = blockIdx.y, y0 = blockIdx.x * DW_ROWS;
   const int nyb = gridDim.x;
   const int tid = threadIdx.x;
   const int CP = C8 * 8;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16_t* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[tp][e] = 0.f;
     if (piece < C8) {
-      for (int yy = y0; yy < y0 + 8 && yy < H; ++yy)
+      for (int yy = y0; yy < y0 + DW_ROWS && yy < H; ++yy)
         for (int xx = pl; xx < W; xx += 8) {
           const long long pix = ((long long)b * H + yy) * W + xx;
           const uint4 dv = *reinterpret_cast<const uint4*>(dy + pix * lddy + piece * 8);
@@ -405,48 +406,68 @@ __global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* _
 }
 
 // LayerNorm backward on bf16 rows: x [rows][ldx] (first C columns normalised), dy [rows][lddy]; dx bf16; dgamma / dbeta partials per
-// workgroup [block][2][C].  16 lanes per row (4 rows per wave), each lane C / 16 (rounded up) columns in steps of 16.
+// workgroup [block][2][C].  16 lanes per row (4 rows per wave); a lane owns the columns j, j + 16, ... of every row it visits, so its
+// share of d gamma / d beta stays in registers (K = ceil(C / 16) pairs) and the 16 lane groups of the workgroup are summed once, at
+// the end, through LDS (no LDS float atomics: they are the slow path on this part).
+template <int K>
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, bf16_t* __restrict__ dx, int lddx,
                                                         float* __restrict__ partial, long long rows, int C, int CPo) {
-  extern __shared__ float sm[];          // [2][C] per-workgroup dgamma / dbeta
+  extern __shared__ float sm[];          // [16 lane groups][2][16 K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, sub = lane >> 4;
-  for (int i = tid; i < 2 * C; i += 256) sm[i] = 0.f;
-  __syncthreads();
   const float invC = 1.0f / (float)C;
+  float dg[K], db[K], gm[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    dg[k] = db[k] = 0.f;
+    gm[k] = j + 16 * k < C ? gamma[j + 16 * k] : 0.f;
+  }
   for (long long m = ((long long)blockIdx.x * 4 + wave) * 4 + sub; m < rows; m += (long long)gridDim.x * 16) {
+    float xv[K], dv[K];
     float s = 0.f, q = 0.f;
-    for (int c = j; c < C; c += 16) {
-      const float v = bf2f(x[m * ldx + c]);
-      s += v;
-      q += v * v;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int c = j + 16 * k;
+      xv[k] = c < C ? bf2f(x[m * ldx + c]) : 0.f;
+      dv[k] = c < C ? bf2f(dy[m * lddy + c]) : 0.f;
+      s += xv[k];
+      q += xv[k] * xv[k];
     }
     const float mean = wave_sum16(s) * invC;
     const float var = fmaxf(wave_sum16(q) * invC - mean * mean, 0.f);
     const float rstd = rsqrtf(var + 1e-5f);
     float s1 = 0.f, s2 = 0.f;
-    for (int c = j; c < C; c += 16) {
-      const float xh = (bf2f(x[m * ldx + c]) - mean) * rstd;
-      const float dg = bf2f(dy[m * lddy + c]) * gamma[c];
-      s1 += dg;
-      s2 += dg * xh;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      xv[k] = j + 16 * k < C ? (xv[k] - mean) * rstd : 0.f;         // x hat
+      const float t = dv[k] * gm[k];
+      s1 += t;
+      s2 += t * xv[k];
     }
     s1 = wave_sum16(s1) * invC;
     s2 = wave_sum16(s2) * invC;
-    for (int c = j; c < CPo; c += 16) {
-      float o = 0.f;
-      if (c < C) {
-        const float xh = (bf2f(x[m * ldx + c]) - mean) * rstd;
-        const float d = bf2f(dy[m * lddy + c]);
-        o = rstd * (d * gamma[c] - s1 - xh * s2);
-        atomicAdd(&sm[c], d * xh);
-        atomicAdd(&sm[C + c], d);
-      }
-      dx[m * lddx + c] = f2bf(o);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int c = j + 16 * k;
+      if (c < CPo) dx[m * lddx + c] = f2bf(c < C ? rstd * (dv[k] * gm[k] - s1 - xv[k] * s2) : 0.f);
+      dg[k] += dv[k] * xv[k];
+      db[k] += dv[k];
     }
   }
+  const int grp = wave * 4 + sub;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    sm[(grp * 2 + 0) * (16 * K) + j + 16 * k] = dg[k];
+    sm[(grp * 2 + 1) * (16 * K) + j + 16 * k] = db[k];
+  }
   __syncthreads();
-  for (int i = tid; i < 2 * C; i += 256) partial[(long long)blockIdx.x * 2 * C + i] = sm[i];
+  for (int i = tid; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float t = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) t += sm[(gq * 2 + which) * (16 * K) + c];
+    partial[(long long)blockIdx.x * 2 * C + i] = t;
+  }
 }
 
 // ---- channel attention ------------------------------------------------------------------------------------------------------------------
@@ -539,8 +560,8 @@ __global__ __launch_bounds__(256) void chan_apply_mat_kernel(const float* __rest
 }  // namespace
 
 int srk_launch_win_attn_bwd_padded(const bf16_t* qkv, int ldq, int CA, const float* bias, const bf16_t* dout, int ldo, bf16_t* dqkv,
-                                   float* dbias, int B, int H, int W, int Hp, int Wp, int wh, int ww, int sy, int sx, int nH, float scale,
-                                   hipStream_t stream);
+                                   float* dbias, float* tiles, int B, int H, int W, int Hp, int Wp, int wh, int ww, int sy, int sx, int nH,
+                                   float scale, hipStream_t stream);
 
 extern "C" {
 
@@ -595,11 +616,14 @@ int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, c
   return srk_check_launch("mul_bwd");
 }
 
+int srk_dwconv3x3_wgrad_chunks(int H) { return H <= 0 ? 0 : (H + DW_ROWS - 1) / DW_ROWS; }
+
 int srk_dwconv3x3_wgrad(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, float* partial, int B, int H, int W, int C8,
                         srk_stream_t stream) {
   SRK_REQUIRE(dy && x && partial, SRK_E_NULL, "dwconv3x3_wgrad: null pointer");
   REQP(B > 0 && H > 0 && W > 0 && C8 > 0 && C8 <= 64 && lddy % 8 == 0 && ldx % 8 == 0, "dwconv3x3_wgrad: bad shape");
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((H + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, partial, H, W, C8);
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((H + DW_ROWS - 1) / DW_ROWS, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, partial, H, W,
+                     C8);
   return srk_check_launch("dwconv3x3_wgrad");
 }
 
@@ -650,15 +674,33 @@ int srk_spatial_gate_train(int what, const uint16_t* x, int ldx, const float* W0
 
 int64_t srk_rowln_bwd_blocks(int64_t rows) {
   const int64_t g = (rows + 15) / 16;
-  return g < 1 ? 1 : (g > 4096 ? 4096 : g);
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
 int srk_rowln_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* gamma, uint16_t* dx, int lddx, float* partial,
                        int64_t rows, int C, int CP_out, srk_stream_t stream) {
   SRK_REQUIRE(dy && x && gamma && dx && partial, SRK_E_NULL, "rowln_bwd: null pointer");
-  REQP(rows > 0 && C > 0 && C <= CP_out && C <= 1024, "rowln_bwd: bad shape");
-  hipLaunchKernelGGL(rowln_bwd_kernel, dim3((unsigned)srk_rowln_bwd_blocks(rows)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, lddy, x,
-                     ldx, gamma, dx, lddx, partial, (long long)rows, C, CP_out);
+  REQP(rows > 0 && C > 0 && C <= CP_out && CP_out <= 512, "rowln_bwd: bad shape (C <= CP_out <= 512)");
+  const dim3 grid((unsigned)srk_rowln_bwd_blocks(rows));
+  hipStream_t st = (hipStream_t)stream;
+  if (CP_out <= 128)
+    hipLaunchKernelGGL(rowln_bwd_kernel<8>, grid, dim3(256), 16 * 2 * 16 * 8 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
+                       (long long)rows, C, CP_out);
+  else if (CP_out <= 384)
+    hipLaunchKernelGGL(rowln_bwd_kernel<24>, grid, dim3(256), 16 * 2 * 16 * 24 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
+                       (long long)rows, C, CP_out);
+  else {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowln_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
+        srk_set_error("rowln_bwd: cannot reserve LDS");
+        return SRK_E_LAUNCH;
+      }
+      configured = true;
+    }
+    hipLaunchKernelGGL(rowln_bwd_kernel<32>, grid, dim3(256), 16 * 2 * 16 * 32 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
+                       (long long)rows, C, CP_out);
+  }
   return srk_check_launch("rowln_bwd");
 }
 
@@ -682,11 +724,16 @@ int srk_chan_apply_mat(const float* M, const uint16_t* src, int ldsrc, const flo
   return srk_check_launch("chan_apply_mat");
 }
 
+size_t srk_win_attention_bwd_padded_scratch(int B, int Hp, int Wp, int wh, int ww, int num_heads) {
+  if (B <= 0 || wh <= 0 || ww <= 0 || num_heads <= 0 || Hp % wh || Wp % ww) return 0;
+  return (size_t)B * (Hp / wh) * (Wp / ww) * num_heads * wh * ww * wh * ww * sizeof(float);
+}
+
 int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, const uint16_t* d_out, int ldo, uint16_t* d_qkv,
-                                 float* d_bias, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x, int num_heads,
-                                 float scale, srk_stream_t stream) {
-  return srk_launch_win_attn_bwd_padded(qkv, ldq, CA, bias, d_out, ldo, d_qkv, d_bias, B, H, W, Hp, Wp, wh, ww, shift_y, shift_x, num_heads, scale,
-                                        (hipStream_t)stream);
+                                 float* d_bias, void* scratch, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x,
+                                 int num_heads, float scale, srk_stream_t stream) {
+  return srk_launch_win_attn_bwd_padded(qkv, ldq, CA, bias, d_out, ldo, d_qkv, d_bias, (float*)scratch, B, H, W, Hp, Wp, wh, ww, shift_y, shift_x,
+                                        num_heads, scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -90,11 +90,10 @@ def _channel_interaction(pm: torch.Tensor, ci: nn.Sequential, stats: Optional[di
 def _channel_attention_matrix(G: torch.Tensor, sq: torch.Tensor, sk: torch.Tensor, temp: torch.Tensor, dh: int) -> torch.Tensor:
     """G [B][h][32][32] = q^T k, sq / sk = column norms^2 of q / k -> softmax((q / |q|)^T (k / |k|) * temperature) over the dh real
     key channels, rows and columns of the padding zero (dat_arch.py:497-503; F.normalize clamps the norm at 1e-12)"""
-    nq = sq.clamp_min(0.0).sqrt().clamp_min(1e-12)
-    nk = sk.clamp_min(0.0).sqrt().clamp_min(1e-12)
-    logits = G / (nq[..., :, None] * nk[..., None, :]) * temp.reshape(1, -1, 1, 1)
-    A = torch.softmax(logits[..., :dh, :dh], dim=-1)
-    return F.pad(A, (0, 32 - dh, 0, 32 - dh))
+    nq = sq[..., :dh].clamp_min(1e-24).sqrt()          # only the real channels enter the graph (the padding's zero norms would put 0 / 0 into
+    nk = sk[..., :dh].clamp_min(1e-24).sqrt()          # the backward of the square root)
+    logits = G[..., :dh, :dh] / (nq[..., :, None] * nk[..., None, :]) * temp.reshape(1, -1, 1, 1)
+    return F.pad(torch.softmax(logits, dim=-1), (0, 32 - dh, 0, 32 - dh))
 
 
 def _dense_bias(sa) -> torch.Tensor:
@@ -402,7 +401,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
 
     def dwconv_grads(dyt, lddy, xptr, ldx, CPc, conv, real_rows):
         """depth-wise 3x3 weight / bias gradient from d y [T][lddy] and the conv's input -> parameter-shaped tensors"""
-        nyb = (H + 7) // 8
+        nyb = int(L.srk_dwconv3x3_wgrad_chunks(H))
         part = torch.empty(B, nyb, 10, CPc, **f32)
         check(L.srk_dwconv3x3_wgrad(dyt, lddy, xptr, ldx, part.data_ptr(), B, H, W, CPc // 8, st))
         g = part.sum((0, 1))                                   # [10][CPc]
@@ -455,6 +454,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
     # ---------------- layers, last to first ----------------
     blocks = S["blocks"]
     pos = len(blocks)
+    attn_scratch = None
     for lay in reversed(S["layers"]):
         li = lay["li"]
         layer = m.layers[li]
@@ -575,8 +575,12 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                     off = br * hb * 32 * 2
                     N = hs * wsz
                     dbias = torch.zeros(hb, N, N, **f32)
+                    need = int(L.srk_win_attention_bwd_padded_scratch(B, Hp, Wp, hs, wsz, hb))
+                    if attn_scratch is None or attn_scratch.numel() < need:
+                        attn_scratch = torch.empty(need, dtype=torch.uint8, device=dev)
                     check(L.srk_win_attention_bwd_padded(qkv.data_ptr() + off, 3 * CA, CA, bk["biases"][br].data_ptr(), d_att.data_ptr() + off, CA,
-                                                         dqkv.data_ptr() + off, dbias.data_ptr(), B, H, W, Hp, Wp, hs, wsz, sy, sx, hb, bk["scale"], st))
+                                                         dqkv.data_ptr() + off, dbias.data_ptr(), attn_scratch.data_ptr(), B, H, W, Hp, Wp, hs, wsz, sy,
+                                                         sx, hb, bk["scale"], st))
                     R = sa.rpe_biases.shape[0]
                     dpos = torch.zeros(R, hb, **f32).index_add_(0, sa.relative_position_index.reshape(-1), dbias.permute(1, 2, 0).reshape(N * N, hb))
                     pos_params = list(sa.pos.parameters())
