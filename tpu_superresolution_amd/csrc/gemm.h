@@ -68,6 +68,8 @@ struct GemmParams {
   float* ln_dbeta;
   int ln_C;               // real channel count
   int ln_rows_window, ln_stats_by_m, ln_out_window;
+  float* ln_skip;         // optional: a second gradient stream of the same rows; the row result becomes outf[t] + dx + ln_skip[t] and is
+                          //   stored to ln_skip[t] (outf untouched), outb = its bf16 copy  (the RSTB skip add folded into the layer's last LN backward)
   // EP_PROJ_RES / EP_RES: optional fused forward LayerNorm of the freshly written residual row (the norm that
   // consumes it next: norm2 after proj, the next block's norm1 / the final norm after fc2 / the RSTB conv).
   // Needs N == one tile.  xn_out row = xn_window ? winrow(xn_geom, token) : token; stats are stored at that row.

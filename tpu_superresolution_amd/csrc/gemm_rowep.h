@@ -329,9 +329,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t 
         const long long ro = p.ln_out_window ? token_to_win_row(p.geom, (int)t) : t;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          float* gp = p.outf + t * p.ldo + 64 * c + 4 * j16;
+          float* gp = (p.ln_skip ? p.ln_skip : p.outf) + t * p.ldo + 64 * c + 4 * j16;
           const float4 old = pf_b[u][c];
           float o[4] = {old.x, old.y, old.z, old.w};
+          if (p.ln_skip) {
+            const float4 sk = *reinterpret_cast<const float4*>(gp);
+            o[0] += sk.x; o[1] += sk.y; o[2] += sk.z; o[3] += sk.w;
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (64 * c + 4 * j16 + e < p.ln_C) {

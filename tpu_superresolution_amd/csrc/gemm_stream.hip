@@ -444,10 +444,15 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
       s1 = wave_sum16(s1) * invC;
       s2 = wave_sum16(s2) * invC;
       const long long ro = maps[64 + lr];
+      float* dst = p.ln_skip ? p.ln_skip : p.outf;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const float4 old = *reinterpret_cast<const float4*>(e0 + C::E32_BYTES + lr * (SBN * 4) + (64 * c + 4 * j16) * 4);
         float o[4] = {old.x, old.y, old.z, old.w};
+        if (p.ln_skip) {             // the layer's skip gradient: a plain load (one launch per layer; no registers to prefetch it into)
+          const float4 sk = *reinterpret_cast<const float4*>(p.ln_skip + t_ * p.ldo + 64 * c + 4 * j16);
+          o[0] += sk.x; o[1] += sk.y; o[2] += sk.z; o[3] += sk.w;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (64 * c + 4 * j16 + e < p.ln_C) {
@@ -456,7 +461,7 @@ __device__ __forceinline__ void stream_epilogue_tile(const GemmParams& p, const 
             cb[c][e] += dy[c][e];
           }
         }
-        st_f4(p.outf + t_ * p.ldo + 64 * c + 4 * j16, make_float4(o[0], o[1], o[2], o[3]));
+        st_f4(dst + t_ * p.ldo + 64 * c + 4 * j16, make_float4(o[0], o[1], o[2], o[3]));
         if (p.outb)
           st_u2(p.outb + ro * p.ldo + 64 * c + 4 * j16, pack_bf4(o[0] * f, o[1] * f, o[2] * f, o[3] * f));
       }

@@ -1170,6 +1170,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         g.rowscale = drop_scale ? drop_scale + ((size_t)last * 2 + 1) * B : nullptr; g.rows_per_sample = HW;
         RUN(resi_backward(c, p->layer_conv[l], w.resi[l], c.at<bf16_t>(w.gxb), c.at<bf16_t>(w.layer_xb[l]), EP_F32_BF16, g, B, H, W));
       }
+      bool skip_folded = false;
       for (int j = depth - 1; j >= 0; --j) {
         const int bi = first + j;
         const BlockW& bw = p->blocks[bi];
@@ -1272,7 +1273,11 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           if (fuse_ln) {   // ... with LN1 backward (+ window reverse + un-roll) fused: gx2[tok] += dx, gxb2 = bf16(gx2 * f_mlp(prev))
             // the bf16 copy feeds the previous block's fc2 gradients; behind the first block of the layer nobody reads it (the RSTB skip
             // add below produces the layer's bf16 gradient)
-            g.outf = c.at<float>(w.gx2); g.outb = j > 0 ? c.at<bf16_t>(w.gxb2) : nullptr; g.geom = geom; g.rowscale = ds_prev_mlp; g.rows_per_sample = HW;
+            // -- the RSTB skip add is folded into this epilogue instead: gx = gx + gx2 + dx, gxb its bf16 copy
+            g.outf = c.at<float>(w.gx2); g.outb = c.at<bf16_t>(j > 0 ? w.gxb2 : w.gxb); g.geom = geom; g.rowscale = j > 0 ? ds_prev_mlp : nullptr;
+            g.rows_per_sample = HW;
+            g.ln_skip = j > 0 ? nullptr : c.at<float>(w.gx);
+            skip_folded = j == 0;
             g.ln_x = c.at<float>(ba.x_in); g.ln_mean = c.at<float>(ba.mean1); g.ln_rstd = c.at<float>(ba.rstd1);
             g.ln_gamma = params + bw.n1w; g.ln_dgamma = grads + bw.n1w; g.ln_dbeta = grads + bw.n1b; g.ln_C = C;
             g.ln_rows_window = 1; g.ln_stats_by_m = 1; g.ln_out_window = 0;
@@ -1288,7 +1293,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
         }
       }
       // RSTB skip: d(layer input) = d(body input) + d(layer output)
-      RUN(srk_launch_add_f32_bf16(c.at<float>(w.gx), c.at<float>(w.gx2), c.at<bf16_t>(w.gxb), (long long)T * CP, st));
+      if (!skip_folded) RUN(srk_launch_add_f32_bf16(c.at<float>(w.gx), c.at<float>(w.gx2), c.at<bf16_t>(w.gxb), (long long)T * CP, st));
       RUN(unpack_group(c, l + 1, grads));
     } else {
       // ---------------- head: patch_embed.norm, long skip, conv_first ----------------
