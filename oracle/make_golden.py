@@ -248,6 +248,30 @@ def gen_g14b():
     save("g14b_dat_pad_split", **arrays)
 
 
+TINY_W16 = dict(img_size=32, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=16, mlp_ratio=2, img_range=1.0,
+                resi_connection="1conv", upscale=2, upsampler="pixelshuffle")
+
+
+def gen_g16():
+    """G16: SwinIR with window_size 16 (network_swinir.py builds any window size; 256-token windows, 961-row bias tables): the
+    classical and the light-weight head, at the training resolution, at a larger size (masks recomputed, :253-257) and at a size
+    that needs the reflect padding of check_image_size (:783-788)."""
+    ns = import_reference("network_swinir")
+    arrays = {}
+    for tag, ups in (("ps", "pixelshuffle"), ("psd", "pixelshuffledirect")):
+        cfg = O.SwinIRConfig(**dict(TINY_W16, upsampler=ups))
+        sd = O.random_state_dict(cfg, seed=17, scale=3.0)
+        m = build_ref_model(ns, cfg, sd)
+        assert list(m.state_dict().keys()) == [k for k, _, _ in O.state_dict_schema(cfg)]
+        arrays[f"{tag}.weight_sha1"] = np.array(sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()])))
+        for hw in ((32, 32), (48, 64), (40, 24)):
+            x = torch.rand(2, 3, *hw, generator=torch.Generator().manual_seed(hw[0] * 7 + hw[1]))
+            with torch.no_grad():
+                arrays[f"{tag}.x_{hw[0]}x{hw[1]}"], arrays[f"{tag}.y_{hw[0]}x{hw[1]}"] = x.numpy(), m(x).numpy()
+    arrays["weight_seed"], arrays["weight_scale"] = np.array(17), np.array(3.0)
+    save("g16_swinir_w16", **arrays)
+
+
 def gen_g14c():
     """G14c: one TRAINING step of the reference's DAT (model.train(): BatchNorm with batch statistics and running-statistic updates,
     drop_path_rate 0 so that the step is deterministic): L1 loss, output, every parameter's gradient and the BatchNorm buffers after
@@ -355,6 +379,8 @@ def main():
         return gen_g14b()
     if "--only-g14c" in sys.argv:
         return gen_g14c()
+    if "--only-g16" in sys.argv:
+        return gen_g16()
     if "--only-g15" in sys.argv:
         return gen_g15()
     gen_g11()
@@ -363,6 +389,7 @@ def main():
     gen_g14b()
     gen_g15()
     gen_g14c()
+    gen_g16()
     ns = import_reference("network_swinir")
 
     # ---- G1/G2: index maps ------------------------------------------------------------------

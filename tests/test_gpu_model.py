@@ -414,3 +414,38 @@ def test_ape_forward_and_gradients_vs_reference_golden():
     from tpu_superresolution_amd._lib import SrkError
     with pytest.raises((SrkError, ValueError, RuntimeError), match="must match the size"):
         build(cfg, sd)(torch.rand(1, 3, 24, 24, device="cuda"))
+
+
+@pytest.mark.parametrize("tag", ["ps", "psd"])
+def test_window_size_16_inference_vs_reference_golden(tag):
+    """G16: SwinIR(window_size=16) -- 256-token windows through the HAT path's attention kernel (swinir_w16.py): the training
+    resolution, a larger size (shift masks for the actual map) and a size that needs reflect padding to a multiple of 16."""
+    from test_oracle_golden import w16_weights
+    from tpu_superresolution_amd._lib import SrkUnsupported
+    g, cfg, sd = w16_weights(tag)
+    m = build(cfg, sd)
+    for hw in ((32, 32), (48, 64), (40, 24)):
+        x = torch.from_numpy(g[f"{tag}.x_{hw[0]}x{hw[1]}"]).cuda()
+        with torch.no_grad():
+            y = m(x).cpu()
+        ref = torch.from_numpy(g[f"{tag}.y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape
+        err = float((y - ref).abs().max())
+        print(f"w16 {tag} {hw}: max err {err:.3e} (|ref| max {float(ref.abs().max()):.3f})")
+        assert err <= 2e-2 * max(1.0, float(ref.abs().max())), (tag, hw)
+    with pytest.raises(SrkUnsupported, match="inference-only"):
+        m.train()(torch.rand(1, 3, 32, 32, device="cuda"))
+
+
+def test_window_size_16_at_width_180_runs_the_fused_kernels():
+    """embed 180 / 6 heads (the classical width) with 16 x 16 windows, 64 x 64 input, batch 8: the persistent GEMMs and the fused
+    MLP are the ones that run (T = 32768 tokens); checked against the oracle."""
+    cfg = O.SwinIRConfig(upscale=2, in_chans=3, img_size=64, window_size=16, img_range=1.0, depths=(2,), embed_dim=180, num_heads=(6,),
+                         mlp_ratio=2, upsampler="pixelshuffledirect", resi_connection="1conv")
+    sd = O.random_state_dict(cfg, seed=5, scale=1.0)
+    m = build(cfg, sd)
+    x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+        want = O.swinir_forward(sd, cfg, x[:2])
+    assert float((y[:2] - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))

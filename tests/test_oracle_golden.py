@@ -413,6 +413,33 @@ def test_g14c_dat_training_step(tag):
         DO.loss_and_grads(sd, cfg, x[:1], t[:1])
 
 
+# ---- G16: SwinIR with window_size 16 --------------------------------------------------------------------------------------------------
+TINY_W16 = dict(img_size=32, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=16, mlp_ratio=2, img_range=1.0,
+                resi_connection="1conv", upscale=2, upsampler="pixelshuffle")
+
+
+def w16_weights(tag):
+    g = load_golden("g16_swinir_w16")
+    cfg = O.SwinIRConfig(**dict(TINY_W16, upsampler={"ps": "pixelshuffle", "psd": "pixelshuffledirect"}[tag]))
+    sd = O.random_state_dict(cfg, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]))
+    digest = _sha1(np.concatenate([v.numpy().astype(np.float32).reshape(-1) for v in sd.values()]))
+    assert digest == str(g[f"{tag}.weight_sha1"])
+    return g, cfg, sd
+
+
+@pytest.mark.parametrize("tag", ["ps", "psd"])
+def test_g16_window_16_forward(tag):
+    """The oracle at window_size 16 (256-token windows, 961-row tables, masks recomputed off the training resolution, reflect padding
+    to a multiple of 16) against the reference's own SwinIR."""
+    g, cfg, sd = w16_weights(tag)
+    for hw in ((32, 32), (48, 64), (40, 24)):
+        x = torch.from_numpy(g[f"{tag}.x_{hw[0]}x{hw[1]}"])
+        with torch.no_grad():
+            y = O.swinir_forward(sd, cfg, x)
+        ref = torch.from_numpy(g[f"{tag}.y_{hw[0]}x{hw[1]}"])
+        assert y.shape == ref.shape and float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (tag, hw)
+
+
 # ---- G15: SwinIR with ape=True ------------------------------------------------------------------------------------------------------
 TINY_APE = dict(img_size=16, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8, mlp_ratio=2, img_range=1.0,
                 resi_connection="1conv", upscale=2, upsampler="pixelshuffle", ape=True)

@@ -9,10 +9,11 @@ kernels behind the C ABI of ``include/srk.h``.  There is no CPU path: a CPU tens
 ``libsrk.so`` or a configuration the kernels do not cover raises.
 
 Covered by the HIP path: window_size 8, head_dim <= 32, embed_dim <= 256, in_chans 1/3, resi_connection '1conv' and
-'3conv', patch_norm=True, ape=False, all four heads -- 'pixelshuffle' (x2/x3/x4/x8), 'pixelshuffledirect'
+'3conv', patch_norm=True, ape (at img_size), use_checkpoint, all four heads -- 'pixelshuffle' (x2/x3/x4/x8), 'pixelshuffledirect'
 (upscale^2 * in_chans <= 16), 'nearest+conv' (x2/x4) and '' (denoising, upscale 1) -- and ``forward_features`` as a callable
-(inference).  Other constructor options (window_size != 8, ape, patch_norm=False, dropout > 0) build the same state_dict but
-raise ``NotImplementedError`` in ``forward``.
+(inference).  window_size 16 runs INFERENCE through the 256-token window attention of the HAT path (``swinir_w16.py``; the two
+pixel-shuffle heads, '1conv').  Other constructor options (other window sizes, patch_norm=False, dropout > 0) build the same
+state_dict but raise ``NotImplementedError`` in ``forward``.
 """
 from __future__ import annotations
 
@@ -411,6 +412,12 @@ class SwinIR(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("this SwinIR runs on MI355X through libsrk only; move the model and input to the GPU "
                                "(no CPU fallback exists in this package)")
+        if self.window_size == 16:        # 256-token windows: host-orchestrated inference on the HAT path's attention kernel
+            if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+                raise SrkUnsupported("SwinIR(window_size=16) on the HIP path is inference-only: call model.eval() / torch.no_grad() "
+                                     "(training runs with window_size 8)")
+            from . import swinir_w16
+            return swinir_w16.forward(self, x)
         eng = self._bind(x.device)
         if not self._param_views_ok(eng):
             self._engine = None
