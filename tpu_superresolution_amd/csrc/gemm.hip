@@ -75,7 +75,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   uint4 ra[4];
   uint4 rw[WPASS];
 
+  // Pixel-shuffled source (the 256 x 256 x 64 gradient of the upsampler): the tiles of one XCD sweep the taps in lock step, and a
+  // source row pair comes back as tap row dy = +1 of tile y - 1, dy = 0 of tile y and dy = -1 of tile y + 1 -- a third of the K loop
+  // apart, by when ~4 MB of other rows have passed through the XCD's 4-MB L2 (measured: 1.94 GB fetched for a 268-MB tensor).
+  // Rotating the tap-row order by the tile's image row makes the three users of a row pair read it at the same time.
+  int krot = 0;
+  if constexpr (LD == LD_CONV3_PS) {
+    const int rows_per_tile = BM > p.W ? BM / p.W : 1;
+    const int ty = (m0 / p.W) / rows_per_tile;
+    krot = ((3 - ty % 3) % 3) * (p.K / BK / 3);
+  }
+  const int nk_all = p.K / BK;
+
   auto load_stage = [&](int kc) {
+    kc = kc + krot < nk_all ? kc + krot : kc + krot - nk_all;
     const int k0 = kc * BK;
     if constexpr (LD == LD_ROWS) {
 #pragma unroll
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int csrc = schunk ^ (srow & 7);
   const bf16_t* zero16 = reinterpret_cast<const bf16_t*>(g_gemm_zero);
   auto issue_stage = [&](int kc, int buf) {
+    kc = kc + krot < nk_all ? kc + krot : kc + krot - nk_all;
     const int k0 = kc * BK;
     const unsigned abase = smem_base + (unsigned)(buf * BM * BK * 2);
     const unsigned wbase = smem_base + (unsigned)((2 * BM * BK + buf * WS_ROWS * BK) * 2);
