@@ -138,8 +138,13 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   caller's workspace (srk_set_wgrad_workspace; the model executor uses a region of its own workspace) and a reduce
  *   kernel adds their sum to dW in a fixed order, or every split adds into dW with fp32 atomics (order-dependent
  *   rounding, ~20 us slower per launch; also what happens when no workspace is registered).
- * Unknown names return SRK_E_UNSUPPORTED. */
+ * Unknown names return SRK_E_UNSUPPORTED.
+ * Scope: the values are per THREAD (thread_local inside the library): srk_set_option / srk_get_option act on the calling thread's
+ * defaults only.  A plan carries its own values -- srk_swinir_plan_set_option -- which replace the thread's for the duration of each
+ * call on that plan, so two plans with different options can live in one process.  The cached device properties and the
+ * "LDS limit raised" flags of the kernels are keyed by device id. */
 int srk_set_option(const char* name, int value);
+int srk_get_option(const char* name, int* value);
 
 /* ---- training-step pieces  (finetune_swinir.py:148-179) ------------------------------------------ */
 /* F.l1_loss(pred, target) (:66-67, :163) forward + backward in one pass; also counts non-finite pred
@@ -449,6 +454,11 @@ typedef struct srk_swinir_plan srk_swinir_plan;
 /* Unsupported configurations return SRK_E_UNSUPPORTED with a message (no CPU fallback exists). */
 int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** plan);
 void srk_swinir_plan_destroy(srk_swinir_plan* plan);
+/* Per-plan option values (names and values as srk_set_option): they apply to every later call on this plan (pack, workspace_bytes,
+ * forward, forward_features, backward) and to nothing else.  Set them before the first srk_swinir_workspace_bytes query: some options
+ * change the workspace layout.  get: *is_set = 1 when the plan carries the value, 0 when the calling thread's default applies. */
+int srk_swinir_plan_set_option(srk_swinir_plan* plan, const char* name, int value);
+int srk_swinir_plan_get_option(const srk_swinir_plan* plan, const char* name, int* value, int* is_set);
 
 /* Flat parameter buffer: fp32, every tensor in the reference's state_dict layout at a 64-float aligned
  * offset, in named_parameters() order. */

@@ -92,3 +92,43 @@ def test_index_entry_points_validate_arguments_without_a_gpu(lib):
     assert h.srk_shift_mask(C.c_void_p(16), 64, 64, 8, 8, None) == -1
     assert b"shift_size must in 0-window_size" in h.srk_last_error()
     assert h.srk_window_partition(C.c_void_p(16), C.c_void_p(16), 1, 13, 8, 3, 8, 4, None) == -1
+
+
+def test_options_are_per_thread_and_per_plan():
+    """SURVEY 8b 'stateless, re-entrant': srk_set_option acts on the calling thread's defaults; a plan carries its own values
+    (srk_swinir_plan_set_option) and its calls leave the thread's defaults as they were.  Host-only: no kernel runs."""
+    import ctypes as C
+    import threading
+    from tpu_superresolution_amd import _lib
+    from tpu_superresolution_amd._lib import check, lib
+    from tpu_superresolution_amd.engine import SwinIRPlan
+    L = lib()
+
+    def get(name):
+        v = C.c_int()
+        check(L.srk_get_option(name.encode(), C.byref(v)))
+        return v.value
+
+    base = get("attn_fused")
+    assert base == 2 and get("mlp_fused") == 1 and get("wgrad_stream_rows") == 32
+    seen = {}
+
+    def other():
+        check(L.srk_set_option(b"attn_fused", 0))
+        seen["other"] = get("attn_fused")
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen["other"] == 0 and get("attn_fused") == base          # another thread's setting is its own
+    plan = SwinIRPlan(img_size=16, in_chans=3, embed_dim=24, depths=(2,), num_heads=(2,), window_size=8, mlp_ratio=2, upscale=2, img_range=1.0,
+                      upsampler="pixelshuffle", options={"attn_fused": 1, "gemm_stream_bm": 32})
+    assert plan.get_option("attn_fused") == (1, True) and plan.get_option("gemm_stream_bm") == (32, True)
+    assert plan.get_option("mlp_fused") == (1, False)
+    assert get("attn_fused") == base and get("gemm_stream_bm") == 0        # setting a plan's option does not touch the thread's default
+    n0 = L.srk_swinir_workspace_bytes(plan.handle, 2, 16, 16, 1)            # a plan call applies and restores
+    assert n0 > 0 and get("attn_fused") == base and get("gemm_stream_bm") == 0
+    with pytest.raises(Exception, match="gemm_stream_bm"):
+        plan.set_option("gemm_stream_bm", 7)
+    with pytest.raises(_lib.SrkUnsupported, match="unknown option"):
+        plan.set_option("no_such_option", 1)
+    assert plan.get_option("gemm_stream_bm") == (32, True)

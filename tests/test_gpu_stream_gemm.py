@@ -316,3 +316,47 @@ def test_fused_mlp_matches_separate_fc1_fc2_kernels(bs, drop):
     for n in res[0][1]:
         rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
         assert rel <= 1e-4, f"{n}: {rel:.3e}"            # bias / LayerNorm gradients use fp32 atomics (order-dependent last bits)
+
+
+def test_two_plans_with_different_options_share_a_process():
+    """Per-plan options (srk_swinir_plan_set_option): model A runs the separate kernels (attn_fused 0, mlp fused off), model B the
+    defaults, their training forwards and backwards interleaved; each equals its own single run under the thread-level setter, and the
+    thread's defaults are untouched afterwards."""
+    import ctypes as C
+    from tpu_superresolution_amd._lib import check, lib
+    cfg = _mid_cfg()
+    sd = O.random_state_dict(cfg, seed=13, scale=1.0)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(8, 3, 64, 64, generator=gen).cuda()
+    t = torch.rand(8, 3, 128, 128, generator=gen).cuda()
+    plain = {"attn_fused": 0, "mlp_fused": 0, "mlp_bwd_fused": 0, "attn_bwd_fused": 0}
+
+    def run_alone(opts):
+        try:
+            for k, v in opts.items():
+                check(lib().srk_set_option(k.encode(), v))
+            m = build(cfg, sd, train=True)
+            out = m(x)
+            torch.nn.functional.l1_loss(out, t).backward()
+            return out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+        finally:
+            for k, v in (("attn_fused", 2), ("mlp_fused", 1), ("mlp_bwd_fused", 1), ("attn_bwd_fused", 1)):
+                check(lib().srk_set_option(k.encode(), v))
+    ref_a, ref_b = run_alone(plain), run_alone({})
+    ma, mb = build(cfg, sd, train=True), build(cfg, sd, train=True)
+    ma.plan_options = dict(plain)
+    ya = ma(x)
+    yb = mb(x)
+    la, lb = torch.nn.functional.l1_loss(ya, t), torch.nn.functional.l1_loss(yb, t)
+    lb.backward()
+    la.backward()
+    torch.cuda.synchronize()
+    for (y, m), ref in (((ya, ma), ref_a), ((yb, mb), ref_b)):
+        assert torch.equal(y.detach().cpu(), ref[0])
+        for n, p in m.named_parameters():
+            rel = float((p.grad.cpu() - ref[1][n]).norm() / (ref[1][n].norm() + 1e-12))
+            assert rel <= 3e-4, (n, rel)           # fp32 atomics in a few reductions: order-dependent last bits
+    assert ma._engine.plan.get_option("attn_fused") == (0, True) and mb._engine.plan.get_option("attn_fused") == (2, False)
+    v = C.c_int()
+    check(lib().srk_get_option(b"attn_fused", C.byref(v)))
+    assert v.value == 2

@@ -149,6 +149,9 @@ _SIGNATURES = {
     "srk_cab_add_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_swinir_plan_create": (_i, [C.POINTER(SwinIRConfig), C.POINTER(_vp)]),
     "srk_swinir_plan_destroy": (None, [_vp]),
+    "srk_swinir_plan_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "srk_swinir_plan_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
+    "srk_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "srk_swinir_param_floats": (_i64, [_vp]),
     "srk_swinir_param_count": (_i, [_vp]),
     "srk_swinir_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i),

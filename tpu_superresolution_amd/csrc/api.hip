@@ -9,6 +9,24 @@
 
 static thread_local char g_err[512] = "";
 
+int srk_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SRK_MAX_DEVICES) return 0;
+  return dev;
+}
+
+int srk_device_cus() {
+  static SrkPerDevice<int> cus;
+  int& c = cus.here();
+  if (c == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    c = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+  }
+  return c;
+}
+
 void srk_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -267,87 +285,100 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
   return SRK_OK;
 }
 
+// ---- options ---------------------------------------------------------------------------------------------------------------------------
+// Every option is a per-THREAD default (thread_local in the kernel sources): srk_set_option changes the calling thread's values and
+// nothing else, a plan carries its own values (srk_swinir_plan_set_option) and applies them around each of its calls.
+namespace {
+
+int tune_get(int which) {
+  int v[4];
+  srk_gemm_stream_tune_get(&v[0], &v[1], &v[2], &v[3]);
+  return v[which];
+}
+int tune_set(int which, int value) {
+  int v[4];
+  srk_gemm_stream_tune_get(&v[0], &v[1], &v[2], &v[3]);
+  v[which] = value;
+  srk_gemm_stream_tune(v[0], v[1], v[2], v[3]);
+  return SRK_OK;
+}
+int wtune_get(int which) {
+  int rows, nt;
+  srk_wgrad_stream_tune_get(&rows, &nt);
+  return which == 0 ? rows : nt;
+}
+
+struct OptEntry {
+  const char* name;
+  int (*get)();
+  int (*set)(int);
+};
+
+const OptEntry kOptions[] = {
+    {"gemm_stream", [] { return srk_gemm_stream_enabled(); }, [](int v) { srk_gemm_stream_enable(v); return (int)SRK_OK; }},
+    {"attn_bwd_fused", [] { return srk_attn_bwd_fused_enabled(); }, [](int v) { srk_attn_bwd_fused_enable(v); return (int)SRK_OK; }},
+    {"attn_fused", [] { return srk_attn_fused_mode(); }, [](int v) { srk_attn_fused_enable(v); return (int)SRK_OK; }},
+    {"wgrad_stream_w8", [] { return srk_wgrad_w8_enabled(); }, [](int v) { srk_wgrad_w8_enable(v); return (int)SRK_OK; }},
+    {"block_light", [] { return srk_block_light_enabled(); }, [](int v) { srk_block_light_enable(v); return (int)SRK_OK; }},
+    {"mlp_bwd_fused", [] { return srk_mlp_bwd_fused_enabled(); }, [](int v) { srk_mlp_bwd_fused_enable(v); return (int)SRK_OK; }},
+    {"mlp_fused", [] { return srk_mlp_fused_enabled(); }, [](int v) { srk_mlp_fused_enable(v); return (int)SRK_OK; }},
+    {"wgrad_stream", [] { return srk_wgrad_stream_enabled(); }, [](int v) { srk_wgrad_stream_enable(v); return (int)SRK_OK; }},
+    {"conv_wgrad_taps", [] { return srk_conv_wgrad_taps_mode(); }, [](int v) { srk_conv_wgrad_taps_enable(v); return (int)SRK_OK; }},
+    {"wgrad_partials", [] { return srk_wgrad_partials_enabled(); }, [](int v) { srk_wgrad_partials_enable(v); return (int)SRK_OK; }},
+    {"wgrad_stream_rows", [] { return wtune_get(0); },
+     [](int v) {
+       SRK_REQUIRE(v == 32 || v == 64, SRK_E_SHAPE, "wgrad_stream_rows: 32/64");
+       srk_wgrad_stream_tune(v, -1);
+       return (int)SRK_OK;
+     }},
+    {"wgrad_stream_nt", [] { return wtune_get(1); }, [](int v) { srk_wgrad_stream_tune(0, v != 0); return (int)SRK_OK; }},
+    {"gemm_stream_bm", [] { return tune_get(0); },
+     [](int v) {
+       SRK_REQUIRE(v == 0 || v == 16 || v == 32 || v == 64, SRK_E_SHAPE, "gemm_stream_bm: 0/16/32/64");
+       return tune_set(0, v);
+     }},
+    {"gemm_stream_ks2", [] { return tune_get(1); }, [](int v) { return tune_set(1, v < 0 ? -1 : (v != 0)); }},
+    {"gemm_stream_split", [] { return tune_get(2); }, [](int v) { return tune_set(2, v < 0 ? -1 : (v != 0)); }},
+    {"gemm_stream_nb", [] { return tune_get(3); },
+     [](int v) {
+       SRK_REQUIRE(v == 0 || v == 4 || v == 8, SRK_E_SHAPE, "gemm_stream_nb: 0/4/8");
+       return tune_set(3, v);
+     }},
+    {"probe_stride", [] { return g_probe.stride; },       // the timing probe is one per process
+     [](int v) {
+       SRK_REQUIRE(v >= 1 && v <= 1024, SRK_E_SHAPE, "probe_stride: 1..1024");
+       g_probe.stride = v;
+       return (int)SRK_OK;
+     }},
+};
+
+const OptEntry* find_option(const char* name) {
+  for (const OptEntry& e : kOptions)
+    if (strcmp(name, e.name) == 0) return &e;
+  return nullptr;
+}
+
+}  // namespace
+
 int srk_set_option(const char* name, int value) {
   REQ_PTR(name);
-  if (strcmp(name, "gemm_stream") == 0) {
-    srk_gemm_stream_enable(value);
-    return SRK_OK;
+  const OptEntry* e = find_option(name);
+  if (!e) {
+    srk_set_error("srk_set_option: unknown option '%s'", name);
+    return SRK_E_UNSUPPORTED;
   }
-  if (strcmp(name, "attn_bwd_fused") == 0) {
-    srk_attn_bwd_fused_enable(value);
-    return SRK_OK;
+  return e->set(value);
+}
+
+int srk_get_option(const char* name, int* value) {
+  REQ_PTR(name); REQ_PTR(value);
+  const OptEntry* e = find_option(name);
+  if (!e) {
+    srk_set_error("srk_get_option: unknown option '%s'", name);
+    return SRK_E_UNSUPPORTED;
   }
-  if (strcmp(name, "attn_fused") == 0) {
-    srk_attn_fused_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "wgrad_stream_w8") == 0) {
-    srk_wgrad_w8_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "block_light") == 0) {
-    srk_block_light_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "mlp_bwd_fused") == 0) {
-    srk_mlp_bwd_fused_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "mlp_fused") == 0) {
-    srk_mlp_fused_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "probe_stride") == 0) {
-    SRK_REQUIRE(value >= 1 && value <= 1024, SRK_E_SHAPE, "probe_stride: 1..1024");
-    g_probe.stride = value;
-    return SRK_OK;
-  }
-  if (strcmp(name, "wgrad_stream") == 0) {
-    srk_wgrad_stream_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "conv_wgrad_taps") == 0) {
-    srk_conv_wgrad_taps_enable(value);
-    return SRK_OK;
-  }
-  if (strcmp(name, "wgrad_stream_rows") == 0) {
-    SRK_REQUIRE(value == 32 || value == 64, SRK_E_SHAPE, "wgrad_stream_rows: 32/64");
-    srk_wgrad_stream_tune(value, -1);
-    return SRK_OK;
-  }
-  if (strcmp(name, "wgrad_stream_nt") == 0) {
-    srk_wgrad_stream_tune(0, value != 0);
-    return SRK_OK;
-  }
-  if (strcmp(name, "wgrad_partials") == 0) {
-    srk_wgrad_partials_enable(value);
-    return SRK_OK;
-  }
-  static int bm = 0, ks2 = -1, split = -1, nb = 0;
-  if (strcmp(name, "gemm_stream_bm") == 0) {
-    SRK_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, SRK_E_SHAPE, "gemm_stream_bm: 0/16/32/64");
-    bm = value;
-    srk_gemm_stream_tune(bm, ks2, split, nb);
-    return SRK_OK;
-  }
-  if (strcmp(name, "gemm_stream_nb") == 0) {
-    SRK_REQUIRE(value == 0 || value == 4 || value == 8, SRK_E_SHAPE, "gemm_stream_nb: 0/4/8");
-    nb = value;
-    srk_gemm_stream_tune(bm, ks2, split, nb);
-    return SRK_OK;
-  }
-  if (strcmp(name, "gemm_stream_split") == 0) {
-    split = value < 0 ? -1 : (value != 0);
-    srk_gemm_stream_tune(bm, ks2, split, nb);
-    return SRK_OK;
-  }
-  if (strcmp(name, "gemm_stream_ks2") == 0) {
-    ks2 = value < 0 ? -1 : (value != 0);
-    srk_gemm_stream_tune(bm, ks2, split, nb);
-    return SRK_OK;
-  }
-  srk_set_error("srk_set_option: unknown option '%s'", name);
-  return SRK_E_UNSUPPORTED;
+  *value = e->get();
+  return SRK_OK;
 }
 
 int srk_probe_trread(const uint16_t* in, uint16_t* out, srk_stream_t stream) {

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, (NT > 16 ? 1 : 3)) void win256_attn_fwd_kernel
 template <int NT, bool OCA, bool TABLE, int QT = 4>
 int launch(const Win256Params& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * NT * 16 * KP * sizeof(bf16_t) + (TABLE ? 1536 * sizeof(float) : 0);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_fwd_kernel<NT, OCA, TABLE, QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {

@@ -379,7 +379,7 @@ template <int NT, bool OCA>
 int launch_bwd(const Win256BwdParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * NT * 16 + 512) * TileAddr<OCA>::PITCH * sizeof(bf16_t) + 256 * 4 * sizeof(float) +
                          2 * (OCA ? 1536 : 964) * sizeof(float);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win256_attn_bwd_kernel<NT, OCA>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {

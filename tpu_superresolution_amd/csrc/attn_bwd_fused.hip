@@ -376,23 +376,14 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     *reinterpret_cast<float4*>(slab + 16 * jt) = make_float4(dbias[jt][0], dbias[jt][1], dbias[jt][2], dbias[jt][3]);
 }
 
-int g_attn_bwd_fused = 1;
-int g_abf_cus = 0;
+thread_local int g_attn_bwd_fused = 1;
 
 }  // namespace
 
 void srk_attn_bwd_fused_enable(int on) { g_attn_bwd_fused = on ? 1 : 0; }
 int srk_attn_bwd_fused_enabled() { return g_attn_bwd_fused; }
 
-static int abf_cus() {
-  if (g_abf_cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    g_abf_cus = -1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_abf_cus = prop.multiProcessorCount;
-  }
-  return g_abf_cus;
-}
+static int abf_cus() { return srk_device_cus(); }
 
 // number of d(bias) slabs the fused backward writes for B_ windows (0: the kernel does not cover this problem)
 int srk_qkv_attn_bwd_slabs(long long B_, int nH, int CA, int K) {
@@ -409,7 +400,7 @@ int srk_launch_qkv_attn_bwd(const bf16_t* xn, int lda, const bf16_t* Wqkv, const
                             WinGeom geom, hipStream_t stream) {
   const int nslab = srk_qkv_attn_bwd_slabs(B_, nH, CA, K);
   if (nslab == 0 || lda % 8 != 0 || ldg % 8 != 0 || B_ * 64 * (long long)(lda > ldg ? lda : ldg) >= (1LL << 31)) return SRK_NOT_COVERED;
-  static int configured = 0;
+  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
   if (!configured) {
     const void* fn = reinterpret_cast<const void*>(&qkv_attn_bwd_kernel);
     hipFuncAttributes attr;

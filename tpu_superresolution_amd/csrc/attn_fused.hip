@@ -479,8 +479,7 @@ __global__ __launch_bounds__(256, 3) void qkv_attn_fwd3_kernel(const FusedParams
 #ifndef SRK_ATTN_FUSED_DEFAULT
 #define SRK_ATTN_FUSED_DEFAULT 2
 #endif
-int g_attn_fused = SRK_ATTN_FUSED_DEFAULT;            // 0 separate kernels, 1 one 8-wave workgroup per CU, 2 three 4-wave workgroups per CU
-int g_fused_cus = 0;
+thread_local int g_attn_fused = SRK_ATTN_FUSED_DEFAULT;            // 0 separate kernels, 1 one 8-wave workgroup per CU, 2 three 4-wave workgroups per CU
 
 }  // namespace
 
@@ -491,14 +490,9 @@ int srk_attn_fused_mode() { return g_attn_fused; }
 int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const float* bias, float scale, bf16_t* qkv,
                             const float* biasd, bf16_t* ao, long long B_, int nH, int CA, int K, WinGeom geom, hipStream_t stream) {
   if (!g_attn_fused || nH != F_NH || CA != F_CA || K != F_K || lda % 8 != 0) return SRK_NOT_COVERED;
-  if (g_fused_cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    g_fused_cus = -1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_fused_cus = prop.multiProcessorCount;
-  }
+  const int g_fused_cus = srk_device_cus();
   if (g_fused_cus < 1 || B_ < g_fused_cus) return SRK_NOT_COVERED;      // fewer windows than CUs: the W preload does not amortise
-  static int configured = 0;
+  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
   if (!configured) {
     const void* fn = reinterpret_cast<const void*>(&qkv_attn_fwd_kernel);
     hipFuncAttributes attr;
@@ -516,7 +510,7 @@ int srk_launch_qkv_attn_fwd(const bf16_t* xn, int lda, const bf16_t* Wt, const f
       configured = 1;
     }
   }
-  static int configured3 = 0;
+  static SrkPerDevice<int> configured3_pd; int& configured3 = configured3_pd.here();
   if (!configured3) {
     const void* fn = reinterpret_cast<const void*>(&qkv_attn_fwd3_kernel);
     hipFuncAttributes attr;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void rect_dbias_reduce_kernel(const float* __r
 template <int QT>
 int launch_rect(const RectBwdParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)4 * 64 * QT * RP * sizeof(bf16_t) + (size_t)64 * QT * 4 * sizeof(float);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&win_rect_attn_bwd_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {

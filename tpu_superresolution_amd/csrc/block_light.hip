@@ -316,11 +316,12 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
   LIGHT_MARK(14);
 }
 
-int g_block_light = 1;
+thread_local int g_block_light = 1;
 
 }  // namespace
 
 void srk_block_light_enable(int on) { g_block_light = on ? 1 : 0; }
+int srk_block_light_enabled() { return g_block_light; }
 
 // SRK_NOT_COVERED (1) when the shape is not the light one (the caller runs the layer-per-launch path).
 int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const float* n1w, const float* n1b, const float* n2w, const float* n2b,
@@ -328,7 +329,7 @@ int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const floa
                                 const float* bproj, const float* b1, const float* b2, const float* biasd, float scale, int C, int CP, int HP,
                                 int nH, int dh, int HID, long long B_, WinGeom geom, hipStream_t stream) {
   if (!g_block_light || CP != 64 || HP != 128 || nH != 6 || dh > 16 || C > 64 || B_ < 1 || B_ >= (1LL << 24)) return SRK_NOT_COVERED;
-  static int configured = 0;
+  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
   if (!configured) {
     const void* fn = reinterpret_cast<const void*>(&swin_block_light_kernel);
     hipFuncAttributes attr;

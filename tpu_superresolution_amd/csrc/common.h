@@ -18,6 +18,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // MFMA 16x16 C/D
 void srk_set_error(const char* fmt, ...);
 int srk_check_launch(const char* what);
 
+// Host-side state that belongs to a DEVICE (the "this kernel's LDS limit has been raised" flags -- hipFuncSetAttribute acts on the
+// current device's copy of the function -- and the cached CU count) is keyed by the current device id, so one process can drive
+// several GPUs through the C ABI.
+constexpr int SRK_MAX_DEVICES = 64;
+int srk_current_device();     // hipGetDevice, clamped to [0, SRK_MAX_DEVICES)
+int srk_device_cus();         // multiProcessorCount of the current device (cached), -1 when it cannot be read
+template <class T>
+struct SrkPerDevice {
+  T v[SRK_MAX_DEVICES] = {};
+  T& here() { return v[srk_current_device()]; }
+};
+
 // optional per-launch timing probe (bench.py roofline leg): HIP events around launches of one kernel family
 enum { FAM_GEMM_LINEAR = 1, FAM_GEMM_CONV = 2, FAM_WGRAD_LINEAR = 3, FAM_WGRAD_CONV = 4, FAM_ATTN_FWD = 5, FAM_ATTN_BWD = 6,
        FAM_LN = 7 };

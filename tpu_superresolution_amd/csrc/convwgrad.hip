@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(const WgradParams 
   }
 }
 
-int g_taps_enabled = 1;
+thread_local int g_taps_enabled = 1;
 
 template <bool SHUF>
 int launch_taps(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (CT + XROWS) * SP * sizeof(bf16_t);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<SHUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -381,12 +381,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_reduce_kernel(const Wgrad
   for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, sum[e]);
 }
 
-int g_taps_dma = 1;
+thread_local int g_taps_dma = 1;
 
 template <bool SHUF>
 int launch_taps_dma(const WgradParams& p, hipStream_t stream) {
   constexpr int lds = TD_RING * TD_STAGE_BYTES;
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_dma_kernel<SHUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess) {
@@ -552,7 +552,7 @@ template <int COP>
 int launch_smallconv_mfma(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP, int Co,
                           hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * 2 * CT * 16 + 2 * XROWS * SP) * sizeof(bf16_t);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_wgrad_mfma_kernel<COP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -664,6 +664,7 @@ void srk_conv_wgrad_taps_enable(int on) {
   g_taps_enabled = on ? 1 : 0;    // 0: per-tap tiles / VALU image head; 1: all-taps register-staged; 2: all-taps LDS-DMA ring (default)
   g_taps_dma = on >= 2 ? 1 : 0;
 }
+int srk_conv_wgrad_taps_mode() { return g_taps_enabled ? (g_taps_dma ? 2 : 1) : 0; }
 
 // SRK_WGRAD_NOT_COVERED when the all-taps kernel does not apply (the caller then uses the per-tap tiles of wgrad.hip)
 int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream) {

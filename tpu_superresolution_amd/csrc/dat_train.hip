@@ -646,7 +646,7 @@ int srk_spatial_gate_train(int what, const uint16_t* x, int ldx, const float* W0
   SRK_REQUIRE(what != 2 || (cA && cB && cC && dx && lddx % 8 == 0), SRK_E_NULL, "spatial_gate_train: apply operands missing");
   const unsigned grid = (unsigned)((rows + 255) / 256);
   const size_t lds = (size_t)(S * C + 256 * 64) * sizeof(float);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
             hipSuccess ||
@@ -690,7 +690,7 @@ int srk_rowln_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx,
     hipLaunchKernelGGL(rowln_bwd_kernel<24>, grid, dim3(256), 16 * 2 * 16 * 24 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
                        (long long)rows, C, CP_out);
   else {
-    static bool configured = false;
+    static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
     if (!configured) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowln_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
         srk_set_error("rowln_bwd: cannot reserve LDS");

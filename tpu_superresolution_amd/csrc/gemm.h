@@ -95,12 +95,16 @@ int srk_launch_gemm(int loader, int epilogue, const GemmParams& p, hipStream_t s
 #define SRK_NOT_COVERED 1
 int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream);
 void srk_gemm_stream_enable(int on);
+int srk_gemm_stream_enabled();
+void srk_gemm_stream_tune_get(int* bm, int* ks2, int* split, int* nb);
 void srk_gemm_stream_tune(int bm, int ks2, int split, int nb);   // 0 / -1 / -1 / 0: defaults
 // Mlp.forward + residual (+ the next LayerNorm) as ONE persistent kernel: out = res + rowscale * (gelu(A W1^T + b1) W2^T + b2),
 // the 16 x 384 hidden tile stays in LDS.  C = 180 (192 padded), hidden 360 (384).  SRK_NOT_COVERED -> run fc1 / fc2 separately.
 int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream);
 void srk_mlp_fused_enable(int on);
+int srk_mlp_fused_enabled();
 // ... and its backward: d u = (d x2 . W2) * gelu'(u) stays in LDS between the two dgrads, the LayerNorm (norm2) backward rides in the
 // second one's epilogue.  A = d x2, Wt = W2^T, aux = u, u_out = d u (output), W2 = W1^T, HP = 384 + the EP_LNBWD fields.
 int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream);
 void srk_mlp_bwd_fused_enable(int on);
+int srk_mlp_bwd_fused_enabled();

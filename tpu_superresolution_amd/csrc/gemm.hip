@@ -357,7 +357,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
   constexpr int BN = NARROW ? 16 : NT * 32;
   constexpr int WS_ROWS = NARROW ? 32 : BN;
   constexpr size_t lds = (size_t)(2 * BM * BK + 2 * WS_ROWS * BK) * sizeof(bf16_t);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LD, EP, NT, NARROW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -1208,15 +1208,15 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(const GemmParams p, 
   }
 }
 
-int g_mlp_fused_enabled = 1;
-int g_mlp_bwd_fused_enabled = 1;
+thread_local int g_mlp_fused_enabled = 1;
+thread_local int g_mlp_bwd_fused_enabled = 1;
 
-int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
-int g_num_cus = 0;
-int g_tune_bm = 0;             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
-int g_tune_ks2 = -1;           // split K over the two wave groups: 0/1, -1 = default
-int g_tune_split = -1;         // role-split kernel (MFMA on the loader waves): 0/1, -1 = default
-int g_tune_nb = 0;             // role-split kernel: epilogue waves 4/8, 0 = default
+thread_local int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
+thread_local int g_num_cus = 0;      // CU count of the device the current launch goes to (refreshed by every launcher)
+thread_local int g_tune_bm = 0;             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
+thread_local int g_tune_ks2 = -1;           // split K over the two wave groups: 0/1, -1 = default
+thread_local int g_tune_split = -1;         // role-split kernel (MFMA on the loader waves): 0/1, -1 = default
+thread_local int g_tune_nb = 0;             // role-split kernel: epilogue waves 4/8, 0 = default
 
 template <typename KernelT>
 int stream_configure(KernelT kernel, int lds, int* state) {
@@ -1246,7 +1246,7 @@ int launch_split(const GemmParams& p, hipStream_t stream) {
   if constexpr (!S::VALID || BM % (4 * NB) != 0 || (NB == 8 && (KC > 3 || EP == EP_LNBWD))) {   // 12 waves: <= 168 VGPRs
     return SRK_NOT_COVERED;
   } else {
-    static int configured = 0;     // 1 usable, -1 not usable
+    static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();     // 1 usable, -1 not usable
     const int rc = stream_configure(&gemm_stream_split_kernel<EP, KC, BM, NB>, S::LDS, &configured);
     if (rc) return rc;
     if (configured < 0) return SRK_NOT_COVERED;
@@ -1265,7 +1265,7 @@ int launch_stream(const GemmParams& p, hipStream_t stream) {
   if constexpr (!C::VALID || (KC == 9 && !KS2)) {
     return SRK_NOT_COVERED;
   } else {
-    static int configured = 0;     // 1 usable, -1 not usable
+    static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();     // 1 usable, -1 not usable
     const int rcc = stream_configure(&gemm_stream_kernel<EP, KC, BM, KS2>, C::LDS, &configured);
     if (rcc) return rcc;
     if (configured < 0) return SRK_NOT_COVERED;
@@ -1337,6 +1337,16 @@ void srk_gemm_stream_tune(int bm, int ks2, int split, int nb) {
   g_tune_split = split;
   g_tune_nb = nb;
 }
+int srk_gemm_stream_enabled() {
+  if (g_stream_enabled < 0) {
+    const char* e = getenv("SRK_GEMM_STREAM");
+    g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_stream_enabled;
+}
+void srk_gemm_stream_tune_get(int* bm, int* ks2, int* split, int* nb) {
+  *bm = g_tune_bm; *ks2 = g_tune_ks2; *split = g_tune_split; *nb = g_tune_nb;
+}
 
 // Returns SRK_NOT_COVERED when the streaming kernel does not cover this problem (the caller then uses the tile kernel).
 int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream) {
@@ -1345,12 +1355,7 @@ int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream
     g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!g_stream_enabled) return SRK_NOT_COVERED;
-  if (g_num_cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    g_num_cus = -1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount & ~7;
-  }
+  g_num_cus = srk_device_cus() & ~7;          // of the CURRENT device (cached per device id)
   if (g_num_cus < 8) return SRK_NOT_COVERED;
   if (p.N % SBN != 0 || p.M % 64 != 0 || p.lda % 8 != 0 || p.N / SBN > g_num_cus / 8) return SRK_NOT_COVERED;
   if (p.M < 64 * g_num_cus) return SRK_NOT_COVERED;            // too few tiles to fill the persistent grid
@@ -1372,6 +1377,7 @@ int srk_launch_gemm_stream(int epilogue, const GemmParams& p, hipStream_t stream
 }
 
 void srk_mlp_fused_enable(int on) { g_mlp_fused_enabled = on ? 1 : 0; }
+int srk_mlp_fused_enabled() { return g_mlp_fused_enabled; }
 
 int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream) {
   if (!g_mlp_fused_enabled) return SRK_NOT_COVERED;
@@ -1380,18 +1386,13 @@ int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream) {
     g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!g_stream_enabled) return SRK_NOT_COVERED;
-  if (g_num_cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    g_num_cus = -1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount & ~7;
-  }
+  g_num_cus = srk_device_cus() & ~7;          // of the CURRENT device (cached per device id)
   if (g_num_cus < 8) return SRK_NOT_COVERED;
   if (p.K != MlpCfg::K1 || p.HP != MlpCfg::HP || p.N != SBN || p.lda % 8 != 0 || p.ldo != SBN) return SRK_NOT_COVERED;
   if (p.M % 64 != 0 || p.M < 64 * g_num_cus || p.M >= (1 << 24)) return SRK_NOT_COVERED;
   if (p.rowscale && (p.rows_per_sample <= 0 || p.rows_per_sample % 64 != 0)) return SRK_NOT_COVERED;
   if (!p.A || !p.Wt || !p.W2 || !p.res || !p.outf || (p.u_out != nullptr) != (p.h_out != nullptr)) return SRK_NOT_COVERED;
-  static int configured = 0;
+  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
   const int rc = stream_configure(&mlp_fused_fwd_kernel, MlpCfg::LDS, &configured);
   if (rc) return rc;
   if (configured < 0) return SRK_NOT_COVERED;       // the build spilled: never run it (scratch traffic would break the counted waits)
@@ -1402,6 +1403,7 @@ int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream) {
 }
 
 void srk_mlp_bwd_fused_enable(int on) { g_mlp_bwd_fused_enabled = on ? 1 : 0; }
+int srk_mlp_bwd_fused_enabled() { return g_mlp_bwd_fused_enabled; }
 
 // A = d x2 bf16 [M][lda], Wt = W2^T [384][192], aux = u [M][HP], u_out = d u [M][HP] (written), W2 = W1^T [192][384]; the
 // LayerNorm-backward fields, outf / outb / geom / rowscale as for EP_LNBWD.  SRK_NOT_COVERED -> run the two GEMMs.
@@ -1412,12 +1414,7 @@ int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream) {
     g_stream_enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!g_stream_enabled) return SRK_NOT_COVERED;
-  if (g_num_cus == 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    g_num_cus = -1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount & ~7;
-  }
+  g_num_cus = srk_device_cus() & ~7;          // of the CURRENT device (cached per device id)
   if (g_num_cus < 8) return SRK_NOT_COVERED;
   if (p.K != MlpBwdCfg::K1 || p.HP != MlpBwdCfg::HP || p.N != SBN || p.lda % 8 != 0 || p.ldo != SBN) return SRK_NOT_COVERED;
   if (p.M % 64 != 0 || p.M < 64 * g_num_cus || p.M >= (1 << 24)) return SRK_NOT_COVERED;
@@ -1425,7 +1422,7 @@ int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream) {
   if (!p.A || !p.Wt || !p.W2 || !p.aux || !p.u_out || !p.outf || !p.ln_x || !p.ln_mean || !p.ln_rstd || !p.ln_gamma || !p.ln_dgamma ||
       !p.ln_dbeta || p.ln_rows_window != 0)
     return SRK_NOT_COVERED;
-  static int configured = 0;
+  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
   const int rc = stream_configure(&mlp_fused_bwd_kernel, MlpBwdCfg::LDS, &configured);
   if (rc) return rc;
   if (configured < 0) return SRK_NOT_COVERED;       // the build spilled: never run it (scratch traffic would break the counted waits)

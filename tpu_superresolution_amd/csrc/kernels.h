@@ -12,6 +12,7 @@ void srk_attn_fused_enable(int on);
 int srk_attn_fused_mode();
 // block_light.hip: one whole Swin block of the light width per launch (inference); SRK_NOT_COVERED when the shape is another
 void srk_block_light_enable(int on);
+int srk_block_light_enabled();
 int srk_launch_swin_block_light(const float* x, float* y, bf16_t* yb, const float* n1w, const float* n1b, const float* n2w, const float* n2b,
                                 const bf16_t* Wqkv, const bf16_t* Wproj, const bf16_t* W1, const bf16_t* W2, const float* bqkv,
                                 const float* bproj, const float* b1, const float* b2, const float* biasd, float scale, int C, int CP, int HP,

@@ -1043,7 +1043,7 @@ int srk_launch_smallconv_dgrad(const float* gy, const float* wgt, bf16_t* dx, in
   // 120 KB of weights: more than the default 64 KB dynamic-LDS limit, well inside the CU's 160 KB
   SRK_REQUIRE(lds <= 160 * 1024, SRK_E_SHAPE, "smallconv dgrad: LDS %zu too large", lds);
   if (lds > 64 * 1024) {
-    static size_t reserved = 0;
+    static SrkPerDevice<size_t> reserved_pd; size_t& reserved = reserved_pd.here();
     if (lds > reserved) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
           hipSuccess) {
@@ -1078,7 +1078,7 @@ int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, floa
   if (CoP == 4) {
     hipLaunchKernelGGL(smallconv_wgrad_kernel<4>, dim3(grid), dim3(threads), lds, stream, x, gy, dW, db, B, H, W, Cin, CinP, Co, ppb);
   } else {
-    static bool configured = false;
+    static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
     if (!configured) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&smallconv_wgrad_kernel<16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {

@@ -86,6 +86,7 @@ struct srk_swinir_plan {
   bool no_shift;               // img_size <= window_size: shift disabled everywhere (:193-196)
   std::vector<ParamEntry> params;
   long long param_floats = 0;
+  std::vector<std::pair<std::string, int>> options;   // the plan's own option values (srk_swinir_plan_set_option), applied around its calls
   std::vector<BlockW> blocks;
   std::vector<int> layer_first_blk;
   std::vector<ResiW> layer_conv;
@@ -230,6 +231,26 @@ struct Arena {
     ws->names[name] = std::make_pair(o, bytes);
     return o;
   }
+};
+
+// The plan's option values replace the calling thread's for the duration of one plan call (the kernel launchers read thread-local
+// values: two plans with different options can share a process, and a thread's defaults are back when the call returns).
+struct PlanOptionScope {
+  std::vector<std::pair<const char*, int>> saved;
+  explicit PlanOptionScope(const srk_swinir_plan* p) {
+    if (!p) return;
+    for (const auto& o : p->options) {
+      int old = 0;
+      if (srk_get_option(o.first.c_str(), &old) != SRK_OK) continue;
+      saved.emplace_back(o.first.c_str(), old);
+      srk_set_option(o.first.c_str(), o.second);
+    }
+  }
+  ~PlanOptionScope() {
+    for (auto it = saved.rbegin(); it != saved.rend(); ++it) srk_set_option(it->first, it->second);
+  }
+  PlanOptionScope(const PlanOptionScope&) = delete;
+  PlanOptionScope& operator=(const PlanOptionScope&) = delete;
 };
 
 // option values that change the workspace layout: a forward re-lays the workspace out when they differ from the laid-out ones
@@ -629,8 +650,39 @@ size_t srk_swinir_packed_bytes(const srk_swinir_plan* plan) {
   return plan ? (size_t)plan->packed_elems * 2 + (size_t)plan->side_floats * 4 : 0;
 }
 
+int srk_swinir_plan_set_option(srk_swinir_plan* plan, const char* name, int value) {
+  SRK_REQUIRE(plan && name, SRK_E_NULL, "plan_set_option: null argument");
+  int old = 0;
+  RUN(srk_get_option(name, &old));              // unknown names fail here
+  const int rc = srk_set_option(name, value);   // validates the value ...
+  int stored = value;
+  if (rc == SRK_OK) srk_get_option(name, &stored);
+  srk_set_option(name, old);                    // ... and leaves the thread's default as it was
+  if (rc != SRK_OK) return rc;
+  for (auto& o : plan->options)
+    if (o.first == name) {
+      o.second = stored;
+      return SRK_OK;
+    }
+  plan->options.emplace_back(name, stored);
+  return SRK_OK;
+}
+
+int srk_swinir_plan_get_option(const srk_swinir_plan* plan, const char* name, int* value, int* is_set) {
+  SRK_REQUIRE(plan && name && value, SRK_E_NULL, "plan_get_option: null argument");
+  for (const auto& o : plan->options)
+    if (o.first == name) {
+      *value = o.second;
+      if (is_set) *is_set = 1;
+      return SRK_OK;
+    }
+  if (is_set) *is_set = 0;
+  return srk_get_option(name, value);           // not set on the plan: the calling thread's default applies
+}
+
 int srk_swinir_pack(srk_swinir_plan* plan, const float* params, void* packed, srk_stream_t stream) {
   SRK_REQUIRE(plan && params && packed, SRK_E_NULL, "pack: null argument");
+  PlanOptionScope opts(plan);
   SRK_REQUIRE(plan->d_descs, SRK_E_STATE, "pack: srk_swinir_const_init has not been called");
   bf16_t* pk = reinterpret_cast<bf16_t*>(packed);
   float* side = const_cast<float*>(side_of(plan, packed));
@@ -645,6 +697,7 @@ int srk_swinir_pack(srk_swinir_plan* plan, const float* params, void* packed, sr
 
 size_t srk_swinir_workspace_bytes(const srk_swinir_plan* plan, int B, int H0, int W0, int training) {
   if (!plan || B <= 0 || H0 <= 0 || W0 <= 0) return 0;
+  PlanOptionScope opts(plan);
   layout_workspace(plan, const_cast<srk_swinir_plan*>(plan)->ws, B, H0, W0, training);
   return plan->ws.total;
 }
@@ -858,6 +911,7 @@ extern "C" {
 int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* packed, const float* x, float* y,
                        void* workspace, int B, int H0, int W0, int training, const float* drop_scale, srk_stream_t stream_) {
   SRK_REQUIRE(plan && params && packed && x && y && workspace, SRK_E_NULL, "forward: null argument");
+  PlanOptionScope opts(plan);
   SRK_REQUIRE(B > 0 && H0 > 0 && W0 > 0, SRK_E_SHAPE, "forward: bad shape B=%d H=%d W=%d", B, H0, W0);
   srk_swinir_plan* p = plan;
   Workspace& w = p->ws;
@@ -942,6 +996,7 @@ int srk_swinir_forward(srk_swinir_plan* plan, const float* params, const void* p
 int srk_swinir_forward_features(srk_swinir_plan* plan, const float* params, const void* packed, const float* f, float* out,
                                 void* workspace, int B, int H, int W, srk_stream_t stream_) {
   SRK_REQUIRE(plan && params && packed && f && out && workspace, SRK_E_NULL, "forward_features: null argument");
+  PlanOptionScope opts(plan);
   SRK_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, SRK_E_SHAPE,
               "forward_features: H and W must be positive multiples of the window size 8 (got %dx%d)", H, W);
   srk_swinir_plan* p = plan;
@@ -1030,6 +1085,7 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
                         void* workspace, int B, int H0, int W0, const float* drop_scale, int seg_begin, int seg_end,
                         srk_stream_t stream_) {
   SRK_REQUIRE(plan && params && packed && grads && d_y && workspace, SRK_E_NULL, "backward: null argument");
+  PlanOptionScope opts(plan);
   srk_swinir_plan* p = plan;
   Workspace& w = p->ws;
   SRK_REQUIRE(w.B == B && w.H0 == H0 && w.W0 == W0 && w.training == 1, SRK_E_STATE,

@@ -71,6 +71,9 @@ void srk_wgrad_partials_enable(int on);
 void srk_wgrad_w8_enable(int on);
 void srk_wgrad_stream_tune(int rows, int nt);   // rows 32/64 (0 = keep), nt 0/1 (-1 = keep)
 int srk_wgrad_partials_enabled();
+int srk_wgrad_stream_enabled();
+int srk_wgrad_w8_enabled();
+void srk_wgrad_stream_tune_get(int* rows, int* nt);
 
 int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);
 
@@ -78,6 +81,7 @@ int srk_launch_wgrad(const WgradParams& p, hipStream_t stream);
 #define SRK_WGRAD_NOT_COVERED 1
 int srk_launch_conv_wgrad_taps(const WgradParams& p, hipStream_t stream);
 void srk_conv_wgrad_taps_enable(int on);
+int srk_conv_wgrad_taps_mode();
 int srk_launch_smallconv_wgrad_mfma(const bf16_t* x, const float* gy, float* dW, float* db, int B, int H, int W, int Cin, int CinP, int Co,
                                     int CoP, hipStream_t stream);
 int srk_launch_imghead_dgrad_mfma(const float* gy, const float* wgt, bf16_t* dx, int B, int H, int W, int Cin, int CinP, int Co, int CoP,

@@ -380,19 +380,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradMulti mp) 
 thread_local const RpbJob* t_rpb = nullptr;     // job offered by srk_launch_wgrad_multi_rpb to the next reduce launch of this thread
 thread_local bool t_rpb_done = false;
 
-int g_wgrad_stream = 1;
-int g_wgrad_rows = 32;      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
-int g_wgrad_nt = 1;         // nt (streaming) cache policy on its operand DMAs
+thread_local int g_wgrad_stream = 1;
+thread_local int g_wgrad_rows = 32;      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
+thread_local int g_wgrad_nt = 1;         // nt (streaming) cache policy on its operand DMAs
 #ifndef SRK_WGRAD_W8_DEFAULT
 #define SRK_WGRAD_W8_DEFAULT 1
 #endif
-int g_wgrad_w8 = SRK_WGRAD_W8_DEFAULT;   // eight waves per workgroup (two per SIMD) in the streaming kernel
-int g_wgrad_partials = 1;   // split partials to scratch slabs + reduce kernel (1) or fp32 atomics straight into dW (0)
+thread_local int g_wgrad_w8 = SRK_WGRAD_W8_DEFAULT;   // eight waves per workgroup (two per SIMD) in the streaming kernel
+thread_local int g_wgrad_partials = 1;   // split partials to scratch slabs + reduce kernel (1) or fp32 atomics straight into dW (0)
 
 template <int TA, int TB, bool CONV>
 int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 64 * ((64 * TA + 16) + (64 * TB + 16)) * sizeof(bf16_t);
-  static bool configured = false;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, TB, CONV>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -436,7 +436,7 @@ int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
                                       &wgrad_stream_kernel<32, false, false>, &wgrad_stream_kernel<32, true, false>,
                                       &wgrad_stream_kernel<64, false, true>,  &wgrad_stream_kernel<64, true, true>,
                                       &wgrad_stream_kernel<32, false, true>,  &wgrad_stream_kernel<32, true, true>};
-      static bool sconf = false;
+      static SrkPerDevice<bool> sconf_pd; bool& sconf = sconf_pd.here();
       if (!sconf) {
         for (KernelFn f : fns)
           if (hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, slds) != hipSuccess) {
@@ -507,6 +507,9 @@ void srk_wgrad_stream_tune(int rows, int nt) {
   if (nt >= 0) g_wgrad_nt = nt ? 1 : 0;
 }
 int srk_wgrad_partials_enabled() { return g_wgrad_partials; }
+int srk_wgrad_stream_enabled() { return g_wgrad_stream; }
+int srk_wgrad_w8_enabled() { return g_wgrad_w8; }
+void srk_wgrad_stream_tune_get(int* rows, int* nt) { *rows = g_wgrad_rows; *nt = g_wgrad_nt; }
 
 // Workspace for the split partials of the streaming weight-gradient kernels.  The caller owns it (kernels never
 // allocate): the model executor binds a region of its arena around the backward pass, the stand-alone entry points use

@@ -28,10 +28,20 @@ class ParamInfo:
 class SwinIRPlan:
     """Owns a srk_swinir_plan (host bookkeeping only)."""
 
+    def set_option(self, name: str, value: int) -> None:
+        """A kernel option of THIS plan (names as srk_set_option): applies to its later calls only, whatever the thread's defaults."""
+        check(lib().srk_swinir_plan_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str):
+        """-> (value, carried by the plan?)"""
+        v, is_set = C.c_int(), C.c_int()
+        check(lib().srk_swinir_plan_get_option(self.handle, name.encode(), C.byref(v), C.byref(is_set)))
+        return v.value, bool(is_set.value)
+
     def __init__(self, *, img_size: int, in_chans: int, embed_dim: int, depths: Sequence[int], num_heads: Sequence[int],
                  window_size: int, mlp_ratio: float, upscale: int, img_range: float, upsampler: str,
                  qk_scale: Optional[float] = None, resi_connection: str = "1conv", use_checkpoint: bool = False,
-                 ape: bool = False):
+                 ape: bool = False, options: Optional[dict] = None):
         # any other upsampler string takes the reference's `else` branch: the denoising head (network_swinir.py:760-762)
         ups = _lib.UPSAMPLERS.get(upsampler, _lib.UPSAMPLER_NONE)
         if resi_connection not in _lib.RESI:
@@ -73,6 +83,8 @@ class SwinIRPlan:
             check(lib().srk_swinir_param_info(handle, i, C.byref(name), C.byref(off), C.byref(numel), C.byref(ndim), C.byref(shape)))
             self.params.append(ParamInfo(name.value.decode(), off.value, numel.value, tuple(shape[j] for j in range(ndim.value))))
         self.num_segments = int(lib().srk_swinir_num_segments(handle))
+        for k, v in (options or {}).items():       # per-plan kernel options (include/srk.h: srk_swinir_plan_set_option)
+            self.set_option(k, v)
         self.segment_ranges: List[Tuple[int, int]] = []
         b, e = C.c_int64(), C.c_int64()
         for s in range(self.num_segments):

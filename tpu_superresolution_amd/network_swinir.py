@@ -339,7 +339,8 @@ class SwinIR(nn.Module):
                                     depths=self.depths, num_heads=self.heads, window_size=self.window_size,
                                     mlp_ratio=self.mlp_ratio, upscale=self.upscale, img_range=self.img_range,
                                     upsampler=self.upsampler, qk_scale=self.qk_scale, resi_connection=self.resi_connection,
-                                    use_checkpoint=self.use_checkpoint, ape=bool(self.ape))
+                                    use_checkpoint=self.use_checkpoint, ape=bool(self.ape),
+                                    options=getattr(self, "plan_options", None))      # per-model kernel options: set model.plan_options = {...} before the first forward
         eng = SwinIREngine(self._plan, device)
         named = dict(self.named_parameters())
         missing = [p.name for p in self._plan.params if p.name not in named]
