@@ -346,6 +346,9 @@ int srk_rowln_bf16(const uint16_t* x, int ldx, const float* gamma, const float* 
 /* spatial_interaction (:322-327, :475-480): gate[t] = sigmoid(b3 + w3 . gelu(W0 x_t + b0)); W0 fp32 [S][CP] (BatchNorm folded, zero at pads) */
 int srk_spatial_gate(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, float b3, int S, float* gate, int64_t rows,
                      int CP, srk_stream_t stream);
+/* the same with b3 read from device memory (a parameter that changes every training step: no host round trip) */
+int srk_spatial_gate_dev(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, const float* b3, int S, float* gate,
+                         int64_t rows, int CP, srk_stream_t stream);
 /* out = a * ga + b * gb with one gate per token (tgate [rows]) and one per (sample, channel) (cgate [B][CP]); tok_gate_on_a selects
  * which operand takes the token gate (:430-436 spatial block: 0; :518-524 channel block: 1).  Gates are post-sigmoid. */
 int srk_dual_gate_combine(const uint16_t* a, const uint16_t* b, const float* cgate, const float* tgate, uint16_t* out, int64_t rows,

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "srk_dwconv3x3": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "srk_rowln_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "srk_spatial_gate": (_i, [_vp, _i, _vp, _vp, _vp, _f, _i, _vp, _i64, _i, _vp]),
+    "srk_spatial_gate_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp]),
     "srk_dual_gate_combine": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_channel_attention_workspace": (_sz, [_i, _i, _i]),
     "srk_channel_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -153,10 +153,11 @@ __global__ __launch_bounds__(256) void rowln_bf16_kernel(const bf16_t* __restric
 // lane j holds channels 64 i + 4 j .. +3 (the LayerNorm layout).  W0: fp32 [S][CP] (zero at pad channels), S <= 16.
 template <int NV>
 __global__ __launch_bounds__(256) void spatial_gate_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ W0,
-                                                           const float* __restrict__ b0, const float* __restrict__ w3, float b3, int S,
-                                                           float* __restrict__ gate, long long rows) {
+                                                           const float* __restrict__ b0, const float* __restrict__ w3, float b3,
+                                                           const float* __restrict__ b3_dev, int S, float* __restrict__ gate, long long rows) {
   constexpr int CP = NV * 64;
   __shared__ float Ws[16 * 256];
+  if (b3_dev) b3 += *b3_dev;           // the last bias from device memory (training: no host read of a parameter per block)
   for (int i = threadIdx.x; i < S * CP; i += 256) Ws[i] = W0[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -345,20 +346,32 @@ int srk_rowln_bf16(const uint16_t* x, int ldx, const float* gamma, const float* 
   return srk_check_launch("rowln_bf16");
 }
 
-int srk_spatial_gate(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, float b3, int S, float* gate, int64_t rows,
-                     int CP, srk_stream_t stream) {
+static int spatial_gate_impl(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, float b3, const float* b3_dev, int S,
+                             float* gate, int64_t rows, int CP, srk_stream_t stream) {
   SRK_REQUIRE(x && W0 && b0 && w3 && gate, SRK_E_NULL, "spatial_gate: null pointer");
   SRK_REQUIRE(rows > 0 && S > 0 && S <= 16 && ldx % 4 == 0, SRK_E_SHAPE, "spatial_gate: S=%d (<= 16)", S);
   const int grid = grid_for(rows, 16, 1024);
 #define SG_CASE(NV)                                                                                                                     \
   if (CP == 64 * NV) {                                                                                                                  \
-    hipLaunchKernelGGL(spatial_gate_kernel<NV>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, W0, b0, w3, b3, S, gate, (long long)rows); \
+    hipLaunchKernelGGL(spatial_gate_kernel<NV>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, W0, b0, w3, b3, b3_dev, S, gate, \
+                       (long long)rows);                                                                                                \
     return srk_check_launch("spatial_gate");                                                                                            \
   }
   SG_CASE(1) SG_CASE(2) SG_CASE(3) SG_CASE(4)
 #undef SG_CASE
   srk_set_error("spatial_gate: CP=%d unsupported (64/128/192/256)", CP);
   return SRK_E_UNSUPPORTED;
+}
+
+int srk_spatial_gate(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, float b3, int S, float* gate, int64_t rows,
+                     int CP, srk_stream_t stream) {
+  return spatial_gate_impl(x, ldx, W0, b0, w3, b3, nullptr, S, gate, rows, CP, stream);
+}
+
+int srk_spatial_gate_dev(const uint16_t* x, int ldx, const float* W0, const float* b0, const float* w3, const float* b3, int S, float* gate,
+                         int64_t rows, int CP, srk_stream_t stream) {
+  SRK_REQUIRE(b3, SRK_E_NULL, "spatial_gate: null pointer");
+  return spatial_gate_impl(x, ldx, W0, b0, w3, 0.f, b3, S, gate, rows, CP, stream);
 }
 
 int srk_dual_gate_combine(const uint16_t* a, const uint16_t* b, const float* cgate, const float* tgate, uint16_t* out, int64_t rows,

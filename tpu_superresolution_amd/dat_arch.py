@@ -271,9 +271,12 @@ class DAT(nn.Module):
             return "interaction / SGFN widths out of the kernels' range"
         return None
 
-    def _pack(self, device) -> Dict[str, torch.Tensor]:
+    def _pack(self, device, for_training: bool = False) -> Dict[str, torch.Tensor]:
+        """for_training: only what the training forward / backward read (no BatchNorm folds, no dense position bias: train mode
+        normalises with batch statistics and evaluates the bias MLP under autograd)."""
         ver = sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
-        if self._packed is not None and self._packed_version == ver and self._packed_device == device:
+        key = (ver, bool(for_training))
+        if self._packed is not None and self._packed_version == key and self._packed_device == device:
             return self._packed
         C_, CP = self.embed_dim, _rup(self.embed_dim, 64)
         hid = int(C_ * self.expansion_factor)
@@ -299,10 +302,13 @@ class DAT(nn.Module):
                     P[pre + "Wproj"] = _pack_linear(at.proj.weight, CP, CA, col_map=hm)
                     P[pre + "bproj"] = _pack_vec(at.proj.bias, CP)
                     # DW-conv branch: conv bias + BatchNorm(eval) folded into scale / shift, channels scattered to the head-padded layout
-                    s, t = bn_fold(at.dwconv[1])
                     w9 = torch.zeros(CA, 9, device=device)
                     w9[hm] = at.dwconv[0].weight.float().reshape(C_, 9)
                     P[pre + "dw_w"] = w9.contiguous()
+                    if for_training:
+                        self._pack_sgfn(P, pre, blk, hid, half, HPh, device)
+                        continue
+                    s, t = bn_fold(at.dwconv[1])
                     P[pre + "dw_s"] = _pack_vec(s, CA, row_map=hm)
                     P[pre + "dw_t"] = _pack_vec(t + at.dwconv[0].bias.float() * s, CA, row_map=hm)
                     ci = at.channel_interaction
@@ -324,7 +330,7 @@ class DAT(nn.Module):
                     P[pre + "si_w0"] = w0.contiguous()
                     P[pre + "si_b0"] = (si[0].bias.float() * s + t).contiguous()
                     P[pre + "si_w3"] = si[3].weight.float().reshape(S2).contiguous()
-                    P[pre + "si_b3"] = si[3].bias.float().reshape(1).cpu()
+                    P[pre + "si_b3"] = si[3].bias.float().reshape(1).contiguous()          # read by the kernel from device memory
                     if bi % 2 == 0:
                         for br, sa in enumerate(at.attns):      # dense bias of the branch: pos MLP on the offsets, gathered by the index
                             pos = sa.pos(sa.rpe_biases.float())
@@ -332,19 +338,7 @@ class DAT(nn.Module):
                             P[pre + f"bias{br}"] = pos[sa.relative_position_index.reshape(-1)].reshape(N, N, -1).permute(2, 0, 1).float().contiguous()
                     else:
                         P[pre + "temp"] = at.temperature.float().reshape(-1).contiguous()
-                    # SGFN: the two halves of the hidden vector each padded to HPh columns
-                    f = blk.ffn
-                    rows = torch.arange(hid, device=device)
-                    rows = torch.where(rows < half, rows, rows - half + HPh)
-                    P[pre + "W1"] = _pack_linear(f.fc1.weight, 2 * HPh, CP, row_map=rows)
-                    P[pre + "b1"] = _pack_vec(f.fc1.bias, 2 * HPh, row_map=rows)
-                    P[pre + "W2"] = _pack_linear(f.fc2.weight, CP, HPh)
-                    P[pre + "b2"] = _pack_vec(f.fc2.bias, CP)
-                    sg9 = torch.zeros(HPh, 9, device=device)
-                    sg9[:half] = f.sg.conv.weight.float().reshape(half, 9)
-                    P[pre + "sg_w"] = sg9.contiguous()
-                    P[pre + "sg_s"] = _pack_vec(torch.ones(half, device=device), HPh)
-                    P[pre + "sg_t"] = _pack_vec(f.sg.conv.bias, HPh)
+                    self._pack_sgfn(P, pre, blk, hid, half, HPh, device)
                 P[f"{li}.Wconv"] = _pack_conv(layer.conv.weight, CP, CP)
                 P[f"{li}.bconv"] = _pack_vec(layer.conv.bias, CP)
             P["Wcab"] = _pack_conv(self.conv_after_body.weight, CP, CP)
@@ -366,8 +360,24 @@ class DAT(nn.Module):
             else:
                 P["Wdirect"] = _pack_conv(self.upsample[0].weight, 16, CP)
                 P["bdirect"] = _pack_vec(self.upsample[0].bias, 16)
-        self._packed, self._packed_version, self._packed_device = P, ver, device
+        self._packed, self._packed_version, self._packed_device = P, key, device
         return P
+
+    def _pack_sgfn(self, P, pre, blk, hid, half, HPh, device):
+        """SGFN: the two halves of the hidden vector each padded to HPh columns"""
+        CP = _rup(self.embed_dim, 64)
+        f = blk.ffn
+        rows = torch.arange(hid, device=device)
+        rows = torch.where(rows < half, rows, rows - half + HPh)
+        P[pre + "W1"] = _pack_linear(f.fc1.weight, 2 * HPh, CP, row_map=rows)
+        P[pre + "b1"] = _pack_vec(f.fc1.bias, 2 * HPh, row_map=rows)
+        P[pre + "W2"] = _pack_linear(f.fc2.weight, CP, HPh)
+        P[pre + "b2"] = _pack_vec(f.fc2.bias, CP)
+        sg9 = torch.zeros(HPh, 9, device=device)
+        sg9[:half] = f.sg.conv.weight.float().reshape(half, 9)
+        P[pre + "sg_w"] = sg9.contiguous()
+        P[pre + "sg_s"] = _pack_vec(torch.ones(half, device=device), HPh)
+        P[pre + "sg_t"] = _pack_vec(f.sg.conv.bias, HPh)
 
     # -- forward -----------------------------------------------------------------------------------------------------------
     def forward_features(self, x):
@@ -396,7 +406,7 @@ class DAT(nn.Module):
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 return DATFunction.apply(self, x, drop, *[p for _, p in self.named_parameters()])
             with torch.no_grad(), torch.cuda.device(x.device):
-                return dat_forward_train(self, x.contiguous().float(), self._pack(x.device), pack_train(self, x.device), drop)[0]
+                return dat_forward_train(self, x.contiguous().float(), self._pack(x.device, True), pack_train(self, x.device), drop)[0]
         with torch.no_grad(), torch.cuda.device(x.device):
             return _dat_forward(self, x.contiguous().float(), self._pack(x.device))
 
@@ -469,8 +479,8 @@ def _dat_forward(m: DAT, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.T
             S1, S2 = P[pre + "ci_w1"].shape[0], P[pre + "si_w0"].shape[0]
             check(L.srk_channel_gate_act(gate_src.data_ptr(), gate_ws.data_ptr(), P[pre + "ci_w1"].data_ptr(), P[pre + "ci_b1"].data_ptr(),
                                          P[pre + "ci_w2"].data_ptr(), P[pre + "ci_b2"].data_ptr(), 1.0, cgate.data_ptr(), B, HW, CA, CA, S1, 1, st))
-            check(L.srk_spatial_gate(tok_src.data_ptr(), CA, P[pre + "si_w0"].data_ptr(), P[pre + "si_b0"].data_ptr(), P[pre + "si_w3"].data_ptr(),
-                                     float(P[pre + "si_b3"]), S2, tgate.data_ptr(), T, CA, st))
+            check(L.srk_spatial_gate_dev(tok_src.data_ptr(), CA, P[pre + "si_w0"].data_ptr(), P[pre + "si_b0"].data_ptr(), P[pre + "si_w3"].data_ptr(),
+                                         P[pre + "si_b3"].data_ptr(), S2, tgate.data_ptr(), T, CA, st))
             check(L.srk_dual_gate_combine(att.data_ptr(), conv.data_ptr(), cgate.data_ptr(), tgate.data_ptr(), comb.data_ptr(), T, HW, CA, tok_on_a, st))
             x1 = torch.empty(T, CP, **f32)
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, comb, P[pre + "Wproj"], T, CP, CA, lda=CA, bias=P[pre + "bproj"], res=cur, outf=x1,

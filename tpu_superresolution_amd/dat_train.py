@@ -264,8 +264,9 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
             tgate = torch.empty(T, **f32)
             w3 = si[3].weight.float().reshape(S2).contiguous()
             w0f, b0f = (w0raw * si_s[:, None]).contiguous(), (b0raw * si_s + si_t).contiguous()          # BatchNorm folded for the forward kernel
-            check(L.srk_spatial_gate(tok_src.data_ptr(), CA, w0f.data_ptr(), b0f.data_ptr(), w3.data_ptr(), float(si[3].bias), S2, tgate.data_ptr(), T,
-                                     CA, st))
+            b3 = si[3].bias.float().contiguous()
+            check(L.srk_spatial_gate_dev(tok_src.data_ptr(), CA, w0f.data_ptr(), b0f.data_ptr(), w3.data_ptr(), b3.data_ptr(), S2, tgate.data_ptr(), T,
+                                         CA, st))
             comb = torch.empty(T, CA, **b16)            # tok_src * cgate + gate_src * tgate  (:430-436 / :518-524)
             check(L.srk_dual_gate_combine(tok_src.data_ptr(), gate_src.data_ptr(), cgate.data_ptr(), tgate.data_ptr(), comb.data_ptr(), T, HW, CA, 0, st))
             x1 = torch.empty(T, CP, **f32)
@@ -330,7 +331,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
     ha = _ha()
     _gemm, _rup, _ptr = ha._gemm, ha._rup, ha._ptr
     dev = dy.device
-    P = m._pack(dev)
+    P = m._pack(dev, True)
     PT = pack_train(m, dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     B, Cin, H, W, Hp, Wp, T = S["B"], S["Cin"], S["H"], S["W"], S["Hp"], S["Wp"], S["T"]
@@ -631,7 +632,7 @@ class DATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, drop, *params):
         with torch.cuda.device(x.device), torch.no_grad():
-            y, saved = dat_forward_train(model, x.contiguous().float(), model._pack(x.device), pack_train(model, x.device), drop)
+            y, saved = dat_forward_train(model, x.contiguous().float(), model._pack(x.device, True), pack_train(model, x.device), drop)
         ctx.model, ctx.saved = model, saved
         return y
 
