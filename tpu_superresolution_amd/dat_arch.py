@@ -32,7 +32,8 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import SrkUnsupported, check, lib
-from .hat_arch import Upsample, _gemm, _head_map, _holder_forward, _pack_conv, _pack_linear, _pack_vec, _ps_map, _ptr, _rup
+from .hat_arch import (Upsample, _cached_map, _gemm, _head_map, _holder_forward, _pack_conv, _pack_linear, _pack_vec, _ps_map, _ptr, _qkv_rows, _rup,
+                       batched_pack)
 
 
 class UpsampleOneStep(nn.Sequential):
@@ -113,6 +114,14 @@ def _rect_mask(H, W, hs, ws, sy, sx):
         return torch.where(v < n - w, 0, torch.where(v < n - s, 1, 2))
     label = (lab(H, hs, sy)[:, None] * 3 + lab(W, ws, sx)[None, :]).view(H // hs, hs, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, hs * ws)
     return torch.where(label[:, None, :] != label[:, :, None], torch.tensor(-100.0), torch.tensor(0.0))
+
+
+def _fc1_rows(hid: int, half: int, HPh: int, device) -> torch.Tensor:
+    """row of the packed fc1 weight of hidden feature r: the two halves of SGFN's hidden vector are each padded to HPh columns"""
+    def make():
+        rows = torch.arange(hid, device=device)
+        return torch.where(rows < half, rows, rows - half + HPh)
+    return _cached_map(("fc1", hid, half, HPh, str(device)), make)
 
 
 def is_shifted(rg_idx: int, b_idx: int) -> bool:
@@ -288,12 +297,12 @@ class DAT(nn.Module):
             s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
             return s, (bn.bias - bn.running_mean * s).float()
 
-        with torch.no_grad():
+        with torch.no_grad(), batched_pack() as pk:
             for li, layer in enumerate(self.layers):
                 nH = self.heads[li]
                 dh, CA = C_ // nH, nH * 32
                 hm = _head_map(nH, dh, device)
-                qkv_rows = torch.cat([w * CA + hm for w in range(3)])
+                qkv_rows = _qkv_rows(nH, dh, device)
                 for bi, blk in enumerate(layer.blocks):
                     pre = f"{li}.{bi}."
                     at = blk.attn
@@ -360,6 +369,7 @@ class DAT(nn.Module):
             else:
                 P["Wdirect"] = _pack_conv(self.upsample[0].weight, 16, CP)
                 P["bdirect"] = _pack_vec(self.upsample[0].bias, 16)
+            pk.resolve(P)
         self._packed, self._packed_version, self._packed_device = P, key, device
         return P
 
@@ -367,8 +377,7 @@ class DAT(nn.Module):
         """SGFN: the two halves of the hidden vector each padded to HPh columns"""
         CP = _rup(self.embed_dim, 64)
         f = blk.ffn
-        rows = torch.arange(hid, device=device)
-        rows = torch.where(rows < half, rows, rows - half + HPh)
+        rows = _fc1_rows(hid, half, HPh, device)
         P[pre + "W1"] = _pack_linear(f.fc1.weight, 2 * HPh, CP, row_map=rows)
         P[pre + "b1"] = _pack_vec(f.fc1.bias, 2 * HPh, row_map=rows)
         P[pre + "W2"] = _pack_linear(f.fc2.weight, CP, HPh)

@@ -30,7 +30,8 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from ._lib import check, lib
-from .hat_train import _arange, _pack_conv_T, _unpack_conv, _unpack_linear
+from .hat_arch import _pack_conv_T
+from .hat_train import _arange, _unpack_conv, _unpack_linear
 
 EPS = 1e-5
 
@@ -114,15 +115,14 @@ def pack_train(m, device) -> Dict[str, torch.Tensor]:
     half = hid // 2
     HPh = ha._rup(half, 64)
     P: Dict[str, torch.Tensor] = {}
-    with torch.no_grad():
-        rows = torch.arange(hid, device=device)
-        rows = torch.where(rows < half, rows, rows - half + HPh)
+    with torch.no_grad(), ha.batched_pack() as pk:
+        rows = _da()._fc1_rows(hid, half, HPh, device)
         P["fc1_rows"] = rows
         for li, layer in enumerate(m.layers):
             nH = m.heads[li]
             dh, CA = C_ // nH, nH * 32
             hm = ha._head_map(nH, dh, device)
-            qkv_rows = torch.cat([w * CA + hm for w in range(3)])
+            qkv_rows = ha._qkv_rows(nH, dh, device)
             for bi, blk in enumerate(layer.blocks):
                 pre = f"{li}.{bi}."
                 at = blk.attn
@@ -154,6 +154,7 @@ def pack_train(m, device) -> Dict[str, torch.Tensor]:
                     k += 1
         P["ones"] = torch.ones(max(2 * HPh, 256), device=device)
         P["zeros"] = torch.zeros(max(2 * HPh, 256), device=device)
+        pk.resolve(P)
     m._packedT, m._packedT_version, m._packedT_device = P, ver, device
     return P
 
@@ -469,7 +470,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             at = blk.attn
             dh, hb = C_ // nH, nH // 2
             hm = ha._head_map(nH, dh, dev)
-            qkv_rows = torch.cat([w_ * CA + hm for w_ in range(3)])
+            qkv_rows = ha._qkv_rows(nH, dh, dev)
             qkv = bk["qkv"]
             v_ptr = qkv.data_ptr() + 2 * CA * 2
             # ---- SGFN: x2 = x1 + f * fc2(x1h * dwconv(LN(x2h))) with (x1h | x2h) = gelu(fc1(norm2 x1)) ----

@@ -199,43 +199,148 @@ def _rup(v, m):
     return (v + m - 1) // m * m
 
 
+# ---- packing helpers -------------------------------------------------------------------------------------------------------------------
+# A model is packed after every optimizer step (training), so the count of tiny torch kernels matters: inside ``batched_pack()`` the
+# helpers only RECORD their request and return a placeholder; ``resolve`` groups requests of the same kind / shape / index maps (the 42
+# qkv weights of HAT, ...), runs each group as ONE stack + scatter + cast and hands out views of the stacked result.  Outside the
+# context they run eagerly, one tensor at a time.
+_MAPS: Dict[tuple, torch.Tensor] = {}
+
+
+def _cached_map(key: tuple, make):
+    t = _MAPS.get(key)
+    if t is None:
+        t = _MAPS[key] = make()
+    return t
+
+
+class _Pending:
+    __slots__ = ("group", "index")
+
+    def __init__(self, group, index):
+        self.group, self.index = group, index
+
+
+class _Packer:
+    def __init__(self):
+        self.groups: Dict[tuple, list] = {}
+
+    def add(self, kind, src, args, maps):
+        key = (kind, tuple(src.shape), src.dtype, src.device, args, tuple(id(m_) if m_ is not None else None for m_ in maps))
+        g = self.groups.setdefault(key, [kind, args, maps, []])
+        g[3].append(src)
+        return _Pending(key, len(g[3]) - 1)
+
+    def resolve(self, P: dict) -> None:
+        done = {}
+        for key, (kind, args, maps, srcs) in self.groups.items():
+            done[key] = _PACK_MANY[kind](torch.stack([t.float() for t in srcs]), *args, *maps)
+        for name, v in P.items():
+            if isinstance(v, _Pending):
+                P[name] = done[v.group][v.index]
+
+
+_ACTIVE: Optional[_Packer] = None
+
+
+class batched_pack:
+    """with batched_pack() as pk: ... P[name] = _pack_linear(...) ...; pk.resolve(P)"""
+
+    def __enter__(self):
+        global _ACTIVE
+        self.prev, _ACTIVE = _ACTIVE, _Packer()
+        return _ACTIVE
+
+    def __exit__(self, *exc):
+        global _ACTIVE
+        _ACTIVE = self.prev
+
+
+def _many_linear(ws, NP, KP, row_map, col_map):
+    n, N, K = ws.shape
+    out = torch.zeros(n, NP, KP, dtype=torch.float32, device=ws.device)
+    rows = row_map if row_map is not None else torch.arange(N, device=ws.device)
+    cols = col_map if col_map is not None else torch.arange(K, device=ws.device)
+    out[:, rows[:, None], cols[None, :]] = ws
+    return out.to(torch.bfloat16)
+
+
+def _many_vec(bs, NP, row_map):
+    n, N = bs.shape
+    out = torch.zeros(n, NP, dtype=torch.float32, device=bs.device)
+    rows = row_map if row_map is not None else torch.arange(N, device=bs.device)
+    out[:, rows] = bs
+    return out
+
+
+def _many_conv(ws, NP, CinP, row_map):
+    n, Cout, Cin = ws.shape[:3]
+    out = torch.zeros(n, NP, 9, CinP, dtype=torch.float32, device=ws.device)
+    rows = row_map if row_map is not None else torch.arange(Cout, device=ws.device)
+    out[:, rows, :, :Cin] = ws.permute(0, 1, 3, 4, 2).reshape(n, Cout, 9, Cin)
+    return out.reshape(n, NP, 9 * CinP).to(torch.bfloat16)
+
+
+def _many_conv_T(ws, NP, CoutP, col_map):
+    n, Cout, Cin = ws.shape[:3]
+    out = torch.zeros(n, NP, 9, CoutP, dtype=torch.float32, device=ws.device)
+    cols = col_map if col_map is not None else torch.arange(Cout, device=ws.device)
+    out[:, :Cin, :, cols] = ws.flip(3, 4).permute(0, 2, 3, 4, 1).reshape(n, Cin, 9, Cout)
+    return out.reshape(n, NP, 9 * CoutP).to(torch.bfloat16)
+
+
+_PACK_MANY = {"linear": _many_linear, "vec": _many_vec, "conv": _many_conv, "convT": _many_conv_T}
+
+
 def _pack_linear(w: torch.Tensor, NP: int, KP: int, row_map=None, col_map=None) -> torch.Tensor:
     """fp32 [N][K] -> bf16 [NP][KP], rows / columns scattered through the given index maps (zero elsewhere)."""
-    out = torch.zeros(NP, KP, dtype=torch.float32, device=w.device)
-    rows = row_map if row_map is not None else torch.arange(w.shape[0], device=w.device)
-    cols = col_map if col_map is not None else torch.arange(w.shape[1], device=w.device)
-    out[rows[:, None], cols[None, :]] = w.float()
-    return out.to(torch.bfloat16).contiguous()
+    if _ACTIVE is not None:
+        return _ACTIVE.add("linear", w, (NP, KP), (row_map, col_map))
+    return _many_linear(w.float()[None], NP, KP, row_map, col_map)[0].contiguous()
 
 
 def _pack_vec(b: Optional[torch.Tensor], NP: int, row_map=None, device=None) -> torch.Tensor:
-    out = torch.zeros(NP, dtype=torch.float32, device=device if b is None else b.device)
-    if b is not None:
-        rows = row_map if row_map is not None else torch.arange(b.shape[0], device=b.device)
-        out[rows] = b.float()
-    return out
+    if b is None:
+        return torch.zeros(NP, dtype=torch.float32, device=device)
+    if _ACTIVE is not None:
+        return _ACTIVE.add("vec", b, (NP,), (row_map,))
+    return _many_vec(b.float()[None], NP, row_map)[0]
 
 
 def _pack_conv(w: torch.Tensor, NP: int, CinP: int, row_map=None) -> torch.Tensor:
     """[Cout][Cin][3][3] -> bf16 [NP][9 * CinP], K tap-major: k = (3 ky + kx) * CinP + ci."""
-    Cout, Cin = w.shape[:2]
-    out = torch.zeros(NP, 9, CinP, dtype=torch.float32, device=w.device)
-    rows = row_map if row_map is not None else torch.arange(Cout, device=w.device)
-    out[rows, :, :Cin] = w.float().permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
-    return out.reshape(NP, 9 * CinP).to(torch.bfloat16).contiguous()
+    if _ACTIVE is not None:
+        return _ACTIVE.add("conv", w, (NP, CinP), (row_map,))
+    return _many_conv(w.float()[None], NP, CinP, row_map)[0].contiguous()
+
+
+def _pack_conv_T(w: torch.Tensor, NP: int, CoutP: int, col_map=None) -> torch.Tensor:
+    """[Cout][Cin][3][3] -> bf16 [NP (input channels)][9 * CoutP]: the dgrad's weight, taps flipped, K = (tap, output channel)."""
+    if _ACTIVE is not None:
+        return _ACTIVE.add("convT", w, (NP, CoutP), (col_map,))
+    return _many_conv_T(w.float()[None], NP, CoutP, col_map)[0].contiguous()
 
 
 def _head_map(nH: int, dh: int, device) -> torch.Tensor:
-    """channel h * dh + d -> padded channel h * 32 + d"""
-    c = torch.arange(nH * dh, device=device)
-    return (c // dh) * 32 + c % dh
+    """channel h * dh + d -> padded channel h * 32 + d   (one tensor per (heads, head_dim, device): the batched packer groups by identity)"""
+    def make():
+        c = torch.arange(nH * dh, device=device)
+        return (c // dh) * 32 + c % dh
+    return _cached_map(("head", nH, dh, str(device)), make)
+
+
+def _qkv_rows(nH: int, dh: int, device) -> torch.Tensor:
+    """row of the packed qkv weight of output feature (which, h, d)"""
+    return _cached_map(("qkv", nH, dh, str(device)), lambda: torch.cat([w * nH * 32 + _head_map(nH, dh, device) for w in range(3)]))
 
 
 def _ps_map(C_out: int, r: int, Cs: int, device) -> torch.Tensor:
     """PixelShuffle conv: original output channel c * r^2 + i * r + j -> packed row (i * r + j) * Cs + c"""
-    n = torch.arange(C_out, device=device)
-    c, ij = n // (r * r), n % (r * r)
-    return ij * Cs + c
+    def make():
+        n = torch.arange(C_out, device=device)
+        c, ij = n // (r * r), n % (r * r)
+        return ij * Cs + c
+    return _cached_map(("ps", C_out, r, Cs, str(device)), make)
 
 
 class HAT(nn.Module):
@@ -364,12 +469,12 @@ class HAT(nn.Module):
         hid = int(C * self.mlp_ratio)
         HP = _rup(hid, 64)
         P: Dict[str, torch.Tensor] = {}
-        with torch.no_grad():
+        with torch.no_grad(), batched_pack() as pk:
             for li, layer in enumerate(self.layers):
                 nH = self.heads[li]
                 dh, CA = C // nH, nH * 32
                 hm = _head_map(nH, dh, device)
-                qkv_rows = torch.cat([w * CA + hm for w in range(3)])
+                qkv_rows = _qkv_rows(nH, dh, device)
 
                 def attn_pack(pre, qkv, proj):
                     P[pre + "Wqkv"] = _pack_linear(qkv.weight, 3 * CA, CP, row_map=qkv_rows)
@@ -418,6 +523,7 @@ class HAT(nn.Module):
                     k += 1
             P["Wlast"] = _pack_conv(self.conv_last.weight, 16, 64)
             P["blast"] = _pack_vec(self.conv_last.bias, 16)
+            pk.resolve(P)
         self._packed, self._packed_version, self._packed_device = P, ver, device
         return P
 

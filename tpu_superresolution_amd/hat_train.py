@@ -36,16 +36,6 @@ def _ha():
 
 
 # ---- packed operands of the backward pass (transposed copies for the dgrads) ---------------------------------------------------
-def _pack_conv_T(w: torch.Tensor, NP: int, CoutP: int, col_map=None) -> torch.Tensor:
-    """[Cout][Cin][3][3] -> bf16 [NP (input channels)][9 * CoutP]: the dgrad's weight, taps flipped, K = (tap, output channel)."""
-    Cout, Cin = w.shape[:2]
-    out = torch.zeros(NP, 9, CoutP, dtype=torch.float32, device=w.device)
-    cols = col_map if col_map is not None else torch.arange(Cout, device=w.device)
-    flipped = w.float().flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout)          # [ci][tap'][co]
-    out[:Cin, :, cols] = flipped
-    return out.reshape(NP, 9 * CoutP).to(torch.bfloat16).contiguous()
-
-
 def pack_transposed(m, device) -> Dict[str, torch.Tensor]:
     ha = _ha()
     ver = sum(p._version for p in m.parameters())
@@ -54,12 +44,13 @@ def pack_transposed(m, device) -> Dict[str, torch.Tensor]:
     C_, CP = m.embed_dim, ha._rup(m.embed_dim, 64)
     HP = ha._rup(int(C_ * m.mlp_ratio), 64)
     P: Dict[str, torch.Tensor] = {}
-    with torch.no_grad():
+    _pack_conv_T = ha._pack_conv_T
+    with torch.no_grad(), ha.batched_pack() as pk:
         for li, layer in enumerate(m.layers):
             nH = m.heads[li]
             dh, CA = C_ // nH, nH * 32
             hm = ha._head_map(nH, dh, device)
-            qkv_rows = torch.cat([w * CA + hm for w in range(3)])
+            qkv_rows = ha._qkv_rows(nH, dh, device)
 
             def attn_T(pre, qkv, proj):
                 P[pre + "WqkvT"] = ha._pack_linear(qkv.weight.t(), CP, 3 * CA, col_map=qkv_rows)        # [c][3 CA]
@@ -89,6 +80,7 @@ def pack_transposed(m, device) -> Dict[str, torch.Tensor]:
                 pm = ha._ps_map(mod.weight.shape[0], r, 64, device)
                 P[f"WupT{k}"] = _pack_conv_T(mod.weight, 64, mod.weight.shape[0], col_map=pm)
                 k += 1
+        pk.resolve(P)
     m._packedT, m._packedT_version, m._packedT_device = P, ver, device
     return P
 
@@ -368,7 +360,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             pre, blk, nH, CA = bk["pre"], bk["blk"], bk["nH"], bk["CA"]
             hab = bk["kind"] == "hab"
             hm = ha._head_map(nH, C_ // nH, dev)
-            qkv_rows = torch.cat([w_ * CA + hm for w_ in range(3)])
+            qkv_rows = ha._qkv_rows(nH, C_ // nH, dev)
             # ---- MLP half: x2 = x1 + f_mlp * fc2(gelu(fc1(norm2(x1)))) ----
             g_mlp = scaled(gxb2, bk["bidx"], 1) if hab else gxb2
             du = torch.empty(T, HP, **b16)

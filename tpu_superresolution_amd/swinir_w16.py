@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import SrkUnsupported, check, lib
-from .hat_arch import _gemm, _head_map, _pack_conv, _pack_linear, _pack_vec, _ps_map, _ptr, _rup
+from .hat_arch import _gemm, _head_map, _pack_conv, _pack_linear, _pack_vec, _ps_map, _ptr, _qkv_rows, _rup, batched_pack
 
 
 def unsupported_reason(m) -> str:
@@ -50,12 +50,12 @@ def pack(m, device) -> Dict[str, torch.Tensor]:
     hid = int(C_ * m.mlp_ratio)
     HP = _rup(hid, 64)
     P: Dict[str, torch.Tensor] = {}
-    with torch.no_grad():
+    with torch.no_grad(), batched_pack() as pk:
         for li, layer in enumerate(m.layers):
             nH = m.heads[li]
             dh, CA = C_ // nH, nH * 32
             hm = _head_map(nH, dh, device)
-            qkv_rows = torch.cat([w * CA + hm for w in range(3)])
+            qkv_rows = _qkv_rows(nH, dh, device)
             for bi, blk in enumerate(layer.residual_group.blocks):
                 pre = f"{li}.{bi}."
                 P[pre + "Wqkv"] = _pack_linear(blk.attn.qkv.weight, 3 * CA, CP, row_map=qkv_rows)
@@ -87,6 +87,7 @@ def pack(m, device) -> Dict[str, torch.Tensor]:
         else:
             P["Wdirect"] = _pack_conv(m.upsample[0].weight, 16, CP)
             P["bdirect"] = _pack_vec(m.upsample[0].bias, 16)
+        pk.resolve(P)
     m._w16_packed, m._w16_version, m._w16_device = P, ver, device
     return P
 
