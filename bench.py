@@ -299,11 +299,17 @@ def bench_hat_train(args):
         model.grad_sync = ListGradSynchronizer()
         model.grad_sync.time_exposed = True
     bs = args.batch or 16
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=0.0)
+    graphed = world == 1 and not args.no_graph        # the step is launch-bound on the host (hundreds of C-ABI calls + small torch ops): one hipGraph
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=0.0, capturable=graphed)
     torch.manual_seed(1234 + rank)
     lr_img, hr_img = synthetic_batch(bs, device, seed=1000 + rank)
+    if graphed:
+        from tpu_superresolution_amd.training import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, max_grad_norm=1.0, warmup=2)
 
     def step():
+        if graphed:
+            return gstep(lr_img, hr_img)
         opt.zero_grad(set_to_none=True)
         loss, bad = l1_loss_checked(model(lr_img), hr_img)
         loss.backward()
@@ -348,6 +354,7 @@ def bench_hat_train(args):
                "config": {"workload": what[1] + "bwd + clip 1.0 + AdamW (torch foreach), 64x64 LR -> 256x256 HR, random-init weights, drop_path 0.1",
                           "batch_per_gpu": bs, "global_batch": bs * world, "parallelism": f"dp{world}", "per_gpu_value": value / world,
                           "ms_per_step_median": step_ms[len(step_ms) // 2], "step_tflops_per_gpu": flop_step / (ms_per_step * 1e-3) / 1e12,
+                          "launch": "one hipGraph replay per step (training.GraphedTrainStep)" if graphed else "eager launches",
                           "final_loss": float(loss)},
                "roofline": {"bound": "mfma", "kernel": f"whole {what[0]} train step", "achieved": flop_step / (ms_per_step * 1e-3) / 1e12,
                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_step / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -406,7 +413,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (BASELINE: 32 for cfg3, 16 for cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="cfg2: time the eager launch loop instead of a hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="cfg2 / --train legs: time the eager launch loop instead of a hipGraph replay")
     ap.add_argument("--train", action="store_true", help="cfg4 / cfg5: time a HAT / DAT TRAIN step (fwd + L1 + bwd + clip + AdamW) instead of inference")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="developer A/B: srk_set_option(NAME, VALUE) before the model is built (repeatable)")

@@ -508,3 +508,48 @@ def test_dat_train_step_pixelshuffledirect_vs_oracle():
     loss, yo, grads, _ = DO.loss_and_grads(sd, cfg, x, t)
     assert float((y.detach().cpu() - yo).abs().max()) <= 2e-2 * float(yo.abs().max())
     _check_grads(m, grads)
+
+
+def test_graphed_train_step_matches_eager_steps():
+    """training.GraphedTrainStep (the whole step -- pack, forward, L1, backward, clip, AdamW -- as one hipGraph replay) against the same
+    steps launched eagerly: losses and weights after four steps on changing batches (drop_path 0; fp32 atomics in a few reductions are
+    the only difference)."""
+    from test_oracle_golden import DAT_TINY
+    from tpu_superresolution_amd.training import GraphedTrainStep, l1_loss_checked
+    cfg = DO.DATConfig(**DAT_TINY)
+    sd = DO.random_state_dict(cfg, seed=31, scale=1.0)
+    gen = torch.Generator().manual_seed(9)
+    batches = [(torch.rand(2, 3, 32, 32, generator=gen).cuda(), torch.rand(2, 3, 64, 64, generator=gen).cuda()) for _ in range(4)]
+    ma, mb = _train_model(cfg, sd), _train_model(cfg, sd)
+    oa = torch.optim.AdamW(ma.parameters(), lr=1e-3, weight_decay=0.0)
+    ob = torch.optim.AdamW(mb.parameters(), lr=1e-3, weight_decay=0.0, capturable=True)
+    gs = GraphedTrainStep(mb, ob, max_grad_norm=1.0, warmup=1)
+    # the graphed stepper warms up with one eager step on its first batch: give the eager model the same extra step
+    oa.zero_grad(set_to_none=True)
+    l0, _ = l1_loss_checked(ma(batches[0][0]), batches[0][1])
+    l0.backward()
+    torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+    oa.step()
+    la, lb = [], []
+    for x, t in batches:
+        oa.zero_grad(set_to_none=True)
+        loss, _ = l1_loss_checked(ma(x), t)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+        oa.step()
+        la.append(float(loss))
+        lg, bad = gs(x, t)
+        lb.append(float(lg))
+        assert int(bad) == 0
+    print("eager", la, "graphed", lb)
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(la, lb))
+    assert lb[-1] < lb[0]
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        # Adam normalises the update: an element whose tiny gradient flips sign between the two runs moves by up to 2 lr per step, and the
+        # parameters whose true gradient is zero (a bias in front of a BatchNorm, a softmax-invariant shift) random-walk on rounding noise
+        if n.endswith(("dwconv.0.bias", "channel_interaction.1.bias", "spatial_interaction.0.bias", "pos3.2.bias")):
+            continue
+        assert float((pa - pb).abs().max()) <= 4e-3 and float((pa - pb).abs().mean()) <= 2e-4, n
+    for (n, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        if n.endswith("num_batches_tracked"):
+            assert int(ba) == int(bb) == 5

@@ -410,7 +410,9 @@ class DAT(nn.Module):
             drop = None
             probs = [blk.drop_path_prob for layer in self.layers for blk in layer.blocks]
             if any(pr > 0 for pr in probs):
-                keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
+                keep = getattr(self, "_keep_cache", None)          # built once per device: a host -> device upload cannot be graph-captured
+                if keep is None or keep.device != x.device:
+                    keep = self._keep_cache = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
                 drop = (torch.rand(len(probs), 2, x.shape[0], device=x.device) < keep).float() / keep
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 return DATFunction.apply(self, x, drop, *[p for _, p in self.named_parameters()])

@@ -549,7 +549,9 @@ class HAT(nn.Module):
             if self.training:
                 probs = [blk.drop_path_prob for layer in self.layers for blk in layer.residual_group.blocks]
                 if any(pr > 0 for pr in probs):
-                    keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
+                    keep = getattr(self, "_keep_cache", None)          # built once per device: a host -> device upload cannot be graph-captured
+                    if keep is None or keep.device != x.device:
+                        keep = self._keep_cache = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
                     drop = (torch.rand(len(probs), 2, x.shape[0], device=x.device) < keep).float() / keep
             return HATFunction.apply(self, x, drop, *[p for _, p in self.named_parameters()])
         with torch.no_grad(), torch.cuda.device(x.device):

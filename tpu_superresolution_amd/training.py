@@ -58,3 +58,51 @@ def assert_finite_step(loss: torch.Tensor, bad: torch.Tensor) -> None:
         raise RuntimeError(f"out has non-finite values: count={nb}")
     if not bool(torch.isfinite(loss)):
         raise RuntimeError("loss has non-finite values")
+
+
+class GraphedTrainStep:
+    """The whole train step of a host-orchestrated model (HAT / DAT: hundreds of C-ABI launches plus the small torch ops between
+    them, launch-bound on the host) captured ONCE into a hipGraph and replayed: forward (activations kept, DropPath factors drawn by
+    the graph-safe generator, BatchNorm running statistics updated in place), L1, the hand-written backward, gradient clipping and
+    the optimizer step.
+
+        step = GraphedTrainStep(model, torch.optim.AdamW(model.parameters(), lr=2e-5, capturable=True), max_grad_norm=1.0)
+        loss, bad = step(lr_batch, hr_batch)        # copies the batch into the graph's static inputs and replays
+
+    Requirements: static batch shape, an optimizer constructed with ``capturable=True``, no gradient all-reduce hook on the model
+    (world size 1: collectives stay outside graphs here), nothing in the step that reads a device value on the host.  The first call
+    runs ``warmup`` eager steps (kernel attributes, caches and workspaces get set up outside the capture), then captures."""
+
+    def __init__(self, model, optimizer, max_grad_norm: float = 1.0, warmup: int = 2):
+        if getattr(model, "grad_sync", None) is not None:
+            raise ValueError("GraphedTrainStep: detach the gradient synchronizer (graph capture is for single-process steps)")
+        self.model, self.opt, self.max_grad_norm, self.warmup = model, optimizer, float(max_grad_norm), int(warmup)
+        self.graph = None
+        self.x = self.t = self.loss = self.bad = None
+
+    def _eager(self, x, t):
+        self.opt.zero_grad(set_to_none=True)
+        loss, bad = l1_loss_checked(self.model(x), t)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        self.opt.step()
+        return loss.detach(), bad
+
+    def __call__(self, lr_img: torch.Tensor, hr_img: torch.Tensor):
+        if self.graph is None:
+            self.x, self.t = lr_img.clone(), hr_img.clone()
+            side = torch.cuda.Stream(device=lr_img.device)
+            side.wait_stream(torch.cuda.current_stream(lr_img.device))
+            with torch.cuda.stream(side):              # warm-up on a side stream, as torch.cuda.graphs asks
+                for _ in range(max(self.warmup, 1)):
+                    self._eager(self.x, self.t)
+            torch.cuda.current_stream(lr_img.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss, self.bad = self._eager(self.x, self.t)
+        elif lr_img.shape != self.x.shape or hr_img.shape != self.t.shape:
+            raise ValueError(f"GraphedTrainStep was captured for {tuple(self.x.shape)} -> {tuple(self.t.shape)}")
+        self.x.copy_(lr_img)
+        self.t.copy_(hr_img)
+        self.graph.replay()
+        return self.loss, self.bad
