@@ -415,6 +415,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg2 / --train legs: time the eager launch loop instead of a hipGraph replay")
     ap.add_argument("--train", action="store_true", help="cfg4 / cfg5: time a HAT / DAT TRAIN step (fwd + L1 + bwd + clip + AdamW) instead of inference")
+    ap.add_argument("--use-checkpoint", action="store_true",
+                    help="cfg3: build the model with use_checkpoint=True (u / h / attention output recomputed in the backward; not the BASELINE config)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="developer A/B: srk_set_option(NAME, VALUE) before the model is built (repeatable)")
     args = ap.parse_args()
@@ -452,7 +454,8 @@ def main():
 
     torch.manual_seed(42)                                  # identical random-init weights on every rank
     model = T.SwinIR(upscale=4, in_chans=3, img_size=64, window_size=8, img_range=1.0, depths=[6] * 6, embed_dim=180,
-                     num_heads=[6] * 6, mlp_ratio=2, upsampler="pixelshuffle", resi_connection="1conv").to(device).train()
+                     num_heads=[6] * 6, mlp_ratio=2, upsampler="pixelshuffle", resi_connection="1conv",
+                     use_checkpoint=args.use_checkpoint).to(device).train()
     dp = DataParallelSwinIR(model)
     dp.attach(device)
     opt = FusedAdamW(model, lr=2e-5, weight_decay=0.0, max_grad_norm=1.0, grad_div=float(world))
@@ -528,7 +531,8 @@ def main():
         out = {"metric": "HR pixels/sec, SwinIR x4 train step, 64x64 LR, bs=32/GPU", "value": value, "unit": "HR pixels/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE cfg3: SwinIR classical x4 (dim 180, 6x6 blocks, window 8) train step = fwd + L1 + bwd "
+               "config": {"workload": ("cfg3 with use_checkpoint=True (NOT the BASELINE line): " if args.use_checkpoint else "") +
+                                      "BASELINE cfg3: SwinIR classical x4 (dim 180, 6x6 blocks, window 8) train step = fwd + L1 + bwd "
                                       "+ clip 1.0 + AdamW, 64x64 LR patches -> 256x256 HR, random-init weights, drop_path 0.1",
                           "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                           "per_gpu_value": value / world,

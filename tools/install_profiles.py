@@ -16,7 +16,7 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.
 # whole step: every kernel of the 4 profiled steps (3 timed + 1 warm-up), bytes per step
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f"{G}/m_pmc_fetch", f"{G}/m_pmc_write", ".",
                        f"{P}/{tag}_pmc_step_traffic.json", "4"], stdout=subprocess.DEVNULL)
-for cfg in ("cfg2", "cfg4", "cfg5", "cfg4_train"):
+for cfg in ("cfg2", "cfg4", "cfg5", "cfg4_train", "cfg5_train", "cfg3_use_checkpoint"):
     if os.path.exists(f"{G}/m_bench_{cfg}.json"):
         shutil.copy(f"{G}/m_bench_{cfg}.json", f"{P}/{tag}_bench_line_{cfg}.json")
     st = glob.glob(f"{G}/m_prof_{cfg}/*/*_kernel_stats.csv")
