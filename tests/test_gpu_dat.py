@@ -257,7 +257,7 @@ def test_dat_train_token_kernels_vs_torch():
     assert _rel(d1.cpu().float(), a1f.grad) <= 5e-3 and _rel(d2.cpu().float(), a2f.grad) <= 5e-3
     assert _rel(dcgp.sum(1).cpu(), cgf.grad) <= 1e-5 and _rel(dsm.cpu(), smf.grad) <= 1e-5
     # LayerNorm backward on a bf16 row slice
-    rows, Cn, CPn = 300, 90, 128
+    rows, Cn, CPn = 300, 90, 128          # C not a multiple of 8: the last 16-byte piece straddles C
     h = _bf(torch.randn(rows, 256, generator=g))
     dyl = _bf(torch.randn(rows, CPn, generator=g))
     gm = torch.rand(Cn, generator=g) + 0.5

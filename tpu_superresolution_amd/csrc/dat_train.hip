@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256) void token_elementwise_kernel(const bf16_t* __
                                                                 const float* __restrict__ A, const float* __restrict__ Bv,
                                                                 const float* __restrict__ Cv, bf16_t* __restrict__ out, int ldo,
                                                                 long long rows, int C8, int rps, int flag) {
-  const long long n = rows * C8;
+  const unsigned n = (unsigned)(rows * C8);              // < 2^31 (checked by the launchers): 32-bit index arithmetic, no 64-bit divisions
   const int CP = C8 * 8;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const long long t = i / C8;
-    const int c = (int)(i - t * C8) * 8;
-    const long long co = (rps > 0 ? (t / rps) * CP : 0) + c;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned tu = i / (unsigned)C8;
+    const int c = (int)(i - tu * (unsigned)C8) * 8;
+    const long long t = tu;
+    const long long co = (rps > 0 ? (long long)(tu / (unsigned)rps) * CP : 0) + c;
     float pf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p) {
       const uint4 pv = *reinterpret_cast<const uint4*>(p + t * ldp + c);
@@ -133,10 +134,11 @@ __global__ __launch_bounds__(256) void token_elementwise_kernel(const bf16_t* __
 __global__ __launch_bounds__(256) void mul_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ a, int lda,
                                                       const bf16_t* __restrict__ b, int ldb, bf16_t* __restrict__ da, int ldda,
                                                       bf16_t* __restrict__ db, int lddb, long long rows, int C8) {
-  const long long n = rows * C8;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const long long t = i / C8;
-    const int c = (int)(i - t * C8) * 8;
+  const unsigned n = (unsigned)(rows * C8);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned tu = i / (unsigned)C8;
+    const int c = (int)(i - tu * (unsigned)C8) * 8;
+    const long long t = tu;
     const uint4 dv = *reinterpret_cast<const uint4*>(dy + t * lddy + c);
     const uint4 av = *reinterpret_cast<const uint4*>(a + t * lda + c);
     const uint4 bv = *reinterpret_cast<const uint4*>(b + t * ldb + c);
@@ -174,26 +176,45 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16_t* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[tp][e] = 0.f;
     if (piece < C8) {
-      for (int yy = y0; yy < y0 + DW_ROWS && yy < H; ++yy)
-        for (int xx = pl; xx < W; xx += 8) {
-          const long long pix = ((long long)b * H + yy) * W + xx;
-          const uint4 dv = *reinterpret_cast<const uint4*>(dy + pix * lddy + piece * 8);
+      // a lane walks a run of consecutive pixels of an image row with the 3 x 3 neighbourhood of x in registers: per pixel one new
+      // column of x (3 loads) and dy instead of 9 + 1 loads
+      const int seg = (W + 7) / 8, x_begin = pl * seg, x_end = min(W, x_begin + seg);
+      auto load8 = [&](const bf16_t* base, int ld, int yy, int xx, float (&v)[8]) {
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          const uint4 u = *reinterpret_cast<const uint4*>(base + (((long long)b * H + yy) * W + xx) * ld + piece * 8);
+          unpack_bf2(u.x, v[0], v[1]); unpack_bf2(u.y, v[2], v[3]); unpack_bf2(u.z, v[4], v[5]); unpack_bf2(u.w, v[6], v[7]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+      };
+      for (int yy = y0; yy < y0 + DW_ROWS && yy < H; ++yy) {
+        float win[3][3][8];                  // [row dy + 1][column dx + 1]
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          load8(x, ldx, yy + r - 1, x_begin - 1, win[r][1]);      // becomes column dx = -1 after the first shift
+          load8(x, ldx, yy + r - 1, x_begin, win[r][2]);
+        }
+        for (int xx = x_begin; xx < x_end; ++xx) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              win[r][0][e] = win[r][1][e];
+              win[r][1][e] = win[r][2][e];
+            }
+            load8(x, ldx, yy + r - 1, xx + 1, win[r][2]);
+          }
           float d[8];
-          unpack_bf2(dv.x, d[0], d[1]); unpack_bf2(dv.y, d[2], d[3]); unpack_bf2(dv.z, d[4], d[5]); unpack_bf2(dv.w, d[6], d[7]);
+          load8(dy, lddy, yy, xx, d);
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[9][e] += d[e];
 #pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const int sy = yy + tp / 3 - 1, sx = xx + tp % 3 - 1;
-            if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
-              const uint4 xv = *reinterpret_cast<const uint4*>(x + (((long long)b * H + sy) * W + sx) * ldx + piece * 8);
-              float v[8];
-              unpack_bf2(xv.x, v[0], v[1]); unpack_bf2(xv.y, v[2], v[3]); unpack_bf2(xv.z, v[4], v[5]); unpack_bf2(xv.w, v[6], v[7]);
+          for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-              for (int e = 0; e < 8; ++e) acc[tp][e] += d[e] * v[e];
-            }
-          }
+            for (int e = 0; e < 8; ++e) acc[tp][e] += d[e] * win[tp / 3][tp % 3][e];
         }
+      }
     }
     // combine the 8 pixel lanes of a piece (lanes tid % 32 == const): through LDS, one channel octet at a time
     for (int e = 0; e < 8; ++e) {
@@ -406,66 +427,89 @@ __global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* _
 }
 
 // LayerNorm backward on bf16 rows: x [rows][ldx] (first C columns normalised), dy [rows][lddy]; dx bf16; dgamma / dbeta partials per
-// workgroup [block][2][C].  16 lanes per row (4 rows per wave); a lane owns the columns j, j + 16, ... of every row it visits, so its
-// share of d gamma / d beta stays in registers (K = ceil(C / 16) pairs) and the 16 lane groups of the workgroup are summed once, at
-// the end, through LDS (no LDS float atomics: they are the slow path on this part).
+// workgroup [block][2][C].  16 lanes per row (4 rows per wave); a lane owns the 8-column pieces j, j + 16, ... of every row it visits
+// (16-byte loads and stores), so its share of d gamma / d beta stays in registers (K pieces of 8) and the 16 lane groups of the
+// workgroup are summed once, at the end, through LDS (no LDS float atomics: they are the slow path on this part).
 template <int K>
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, bf16_t* __restrict__ dx, int lddx,
                                                         float* __restrict__ partial, long long rows, int C, int CPo) {
-  extern __shared__ float sm[];          // [16 lane groups][2][16 K]
+  extern __shared__ float sm[];          // [16 lane groups][2][128 K]
+  constexpr int W = 128 * K;             // columns covered by the K pieces of the 16 lanes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, sub = lane >> 4;
   const float invC = 1.0f / (float)C;
-  float dg[K], db[K], gm[K];
+  float dg[K][8], db[K][8], gm[K][8];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    dg[k] = db[k] = 0.f;
-    gm[k] = j + 16 * k < C ? gamma[j + 16 * k] : 0.f;
-  }
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (j + 16 * k) * 8 + e;
+      dg[k][e] = db[k][e] = 0.f;
+      gm[k][e] = c < C ? gamma[c] : 0.f;
+    }
   for (long long m = ((long long)blockIdx.x * 4 + wave) * 4 + sub; m < rows; m += (long long)gridDim.x * 16) {
-    float xv[K], dv[K];
+    float xv[K][8], dv[K][8];
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int c = j + 16 * k;
-      xv[k] = c < C ? bf2f(x[m * ldx + c]) : 0.f;
-      dv[k] = c < C ? bf2f(dy[m * lddy + c]) : 0.f;
-      s += xv[k];
-      q += xv[k] * xv[k];
+      const int c0 = (j + 16 * k) * 8;
+      uint4 xu = make_uint4(0, 0, 0, 0), du = make_uint4(0, 0, 0, 0);
+      if (c0 < C) {                      // a piece that straddles C reads up to 7 columns of the rows' padding (< CP_out <= row stride)
+        xu = *reinterpret_cast<const uint4*>(x + m * ldx + c0);
+        du = *reinterpret_cast<const uint4*>(dy + m * lddy + c0);
+      }
+      unpack_bf2(xu.x, xv[k][0], xv[k][1]); unpack_bf2(xu.y, xv[k][2], xv[k][3]); unpack_bf2(xu.z, xv[k][4], xv[k][5]); unpack_bf2(xu.w, xv[k][6], xv[k][7]);
+      unpack_bf2(du.x, dv[k][0], dv[k][1]); unpack_bf2(du.y, dv[k][2], dv[k][3]); unpack_bf2(du.z, dv[k][4], dv[k][5]); unpack_bf2(du.w, dv[k][6], dv[k][7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (c0 + e >= C) xv[k][e] = dv[k][e] = 0.f;
+        s += xv[k][e];
+        q += xv[k][e] * xv[k][e];
+      }
     }
     const float mean = wave_sum16(s) * invC;
     const float var = fmaxf(wave_sum16(q) * invC - mean * mean, 0.f);
     const float rstd = rsqrtf(var + 1e-5f);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      xv[k] = j + 16 * k < C ? (xv[k] - mean) * rstd : 0.f;         // x hat
-      const float t = dv[k] * gm[k];
-      s1 += t;
-      s2 += t * xv[k];
-    }
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xv[k][e] = (j + 16 * k) * 8 + e < C ? (xv[k][e] - mean) * rstd : 0.f;         // x hat
+        const float t = dv[k][e] * gm[k][e];
+        s1 += t;
+        s2 += t * xv[k][e];
+      }
     s1 = wave_sum16(s1) * invC;
     s2 = wave_sum16(s2) * invC;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int c = j + 16 * k;
-      if (c < CPo) dx[m * lddx + c] = f2bf(c < C ? rstd * (dv[k] * gm[k] - s1 - xv[k] * s2) : 0.f);
-      dg[k] += dv[k] * xv[k];
-      db[k] += dv[k];
+      const int c0 = (j + 16 * k) * 8;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = c0 + e < C ? rstd * (dv[k][e] * gm[k][e] - s1 - xv[k][e] * s2) : 0.f;
+        dg[k][e] += dv[k][e] * xv[k][e];
+        db[k][e] += dv[k][e];
+      }
+      if (c0 < CPo)
+        *reinterpret_cast<uint4*>(dx + m * lddx + c0) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
     }
   }
   const int grp = wave * 4 + sub;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    sm[(grp * 2 + 0) * (16 * K) + j + 16 * k] = dg[k];
-    sm[(grp * 2 + 1) * (16 * K) + j + 16 * k] = db[k];
-  }
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sm[(grp * 2 + 0) * W + (j + 16 * k) * 8 + e] = dg[k][e];
+      sm[(grp * 2 + 1) * W + (j + 16 * k) * 8 + e] = db[k][e];
+    }
   __syncthreads();
   for (int i = tid; i < 2 * C; i += 256) {
     const int which = i / C, c = i - which * C;
     float t = 0.f;
 #pragma unroll
-    for (int gq = 0; gq < 16; ++gq) t += sm[(gq * 2 + which) * (16 * K) + c];
+    for (int gq = 0; gq < 16; ++gq) t += sm[(gq * 2 + which) * W + c];
     partial[(long long)blockIdx.x * 2 * C + i] = t;
   }
 }
@@ -581,7 +625,7 @@ int srk_chan_stats(const uint16_t* p, int ldp, const uint16_t* q, int ldq, float
 int srk_affine_act_bf16(const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out, int ldo, int64_t rows, int C8,
                         int rows_per_sample, int act, srk_stream_t stream) {
   SRK_REQUIRE(x && scale && shift && out, SRK_E_NULL, "affine_act: null pointer");
-  REQP(rows > 0 && C8 > 0 && ldx % 8 == 0 && ldo % 8 == 0, "affine_act: bad shape");
+  REQP(rows > 0 && C8 > 0 && rows * C8 < (1LL << 31) && ldx % 8 == 0 && ldo % 8 == 0, "affine_act: bad shape");
   hipLaunchKernelGGL(token_elementwise_kernel<0>, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16_t*)nullptr, 0,
                      scale, shift, (const float*)nullptr, out, ldo, (long long)rows, C8, rows_per_sample, act);
   return srk_check_launch("affine_act");
@@ -590,7 +634,7 @@ int srk_affine_act_bf16(const uint16_t* x, int ldx, const float* scale, const fl
 int srk_dgelu_affine_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out,
                           int ldo, int64_t rows, int C8, srk_stream_t stream) {
   SRK_REQUIRE(dy && x && scale && shift && out, SRK_E_NULL, "dgelu_affine: null pointer");
-  REQP(rows > 0 && C8 > 0 && lddy % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "dgelu_affine: bad shape");
+  REQP(rows > 0 && C8 > 0 && rows * C8 < (1LL << 31) && lddy % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "dgelu_affine: bad shape");
   hipLaunchKernelGGL(token_elementwise_kernel<1>, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, scale, shift,
                      (const float*)nullptr, out, ldo, (long long)rows, C8, 0, 0);
   return srk_check_launch("dgelu_affine");
@@ -599,7 +643,7 @@ int srk_dgelu_affine_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int l
 int srk_lincomb2_bf16(const uint16_t* p, int ldp, const uint16_t* q, int ldq, const float* A, const float* Bc, const float* Cc, uint16_t* out,
                       int ldo, int64_t rows, int C8, int rows_per_sample, int accumulate, srk_stream_t stream) {
   SRK_REQUIRE(out, SRK_E_NULL, "lincomb2: null pointer");
-  REQP(rows > 0 && C8 > 0 && ldo % 8 == 0 && (p == nullptr || ldp % 8 == 0) && (q == nullptr || ldq % 8 == 0) && (A == nullptr || p != nullptr) &&
+  REQP(rows > 0 && C8 > 0 && rows * C8 < (1LL << 31) && ldo % 8 == 0 && (p == nullptr || ldp % 8 == 0) && (q == nullptr || ldq % 8 == 0) && (A == nullptr || p != nullptr) &&
            (Bc == nullptr || q != nullptr),
        "lincomb2: bad shape");
   hipLaunchKernelGGL(token_elementwise_kernel<2>, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, p, ldp, q, ldq, A, Bc, Cc, out,
@@ -610,7 +654,7 @@ int srk_lincomb2_bf16(const uint16_t* p, int ldp, const uint16_t* q, int ldq, co
 int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* da, int ldda, uint16_t* db,
                      int lddb, int64_t rows, int C8, srk_stream_t stream) {
   SRK_REQUIRE(dy && a && b && da && db, SRK_E_NULL, "mul_bwd: null pointer");
-  REQP(rows > 0 && C8 > 0 && (lddy | lda | ldb | ldda | lddb) % 8 == 0, "mul_bwd: bad shape");
+  REQP(rows > 0 && C8 > 0 && rows * C8 < (1LL << 31) && (lddy | lda | ldb | ldda | lddb) % 8 == 0, "mul_bwd: bad shape");
   hipLaunchKernelGGL(mul_bwd_kernel, dim3(grid_cap(rows * C8)), dim3(256), 0, (hipStream_t)stream, dy, lddy, a, lda, b, ldb, da, ldda, db, lddb,
                      (long long)rows, C8);
   return srk_check_launch("mul_bwd");
@@ -680,27 +724,29 @@ int64_t srk_rowln_bwd_blocks(int64_t rows) {
 int srk_rowln_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const float* gamma, uint16_t* dx, int lddx, float* partial,
                        int64_t rows, int C, int CP_out, srk_stream_t stream) {
   SRK_REQUIRE(dy && x && gamma && dx && partial, SRK_E_NULL, "rowln_bwd: null pointer");
-  REQP(rows > 0 && C > 0 && C <= CP_out && CP_out <= 512, "rowln_bwd: bad shape (C <= CP_out <= 512)");
+  REQP(rows > 0 && C > 0 && C <= CP_out && CP_out % 8 == 0 && CP_out <= 512 && (lddy | ldx | lddx) % 8 == 0 && lddy >= CP_out && ldx >= CP_out &&
+           lddx >= CP_out,
+       "rowln_bwd: bad shape (CP_out and the row strides multiples of 8, C <= CP_out <= 512 <= strides)");
   const dim3 grid((unsigned)srk_rowln_bwd_blocks(rows));
   hipStream_t st = (hipStream_t)stream;
+  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowln_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2 * 384 * 4) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&rowln_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2 * 512 * 4) != hipSuccess) {
+      srk_set_error("rowln_bwd: cannot reserve LDS");
+      return SRK_E_LAUNCH;
+    }
+    configured = true;
+  }
   if (CP_out <= 128)
-    hipLaunchKernelGGL(rowln_bwd_kernel<8>, grid, dim3(256), 16 * 2 * 16 * 8 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
+    hipLaunchKernelGGL(rowln_bwd_kernel<1>, grid, dim3(256), 16 * 2 * 128 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
                        (long long)rows, C, CP_out);
   else if (CP_out <= 384)
-    hipLaunchKernelGGL(rowln_bwd_kernel<24>, grid, dim3(256), 16 * 2 * 16 * 24 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
+    hipLaunchKernelGGL(rowln_bwd_kernel<3>, grid, dim3(256), 16 * 2 * 384 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
                        (long long)rows, C, CP_out);
-  else {
-    static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
-    if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowln_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
-        srk_set_error("rowln_bwd: cannot reserve LDS");
-        return SRK_E_LAUNCH;
-      }
-      configured = true;
-    }
-    hipLaunchKernelGGL(rowln_bwd_kernel<32>, grid, dim3(256), 16 * 2 * 16 * 32 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
+  else
+    hipLaunchKernelGGL(rowln_bwd_kernel<4>, grid, dim3(256), 16 * 2 * 512 * sizeof(float), st, dy, lddy, x, ldx, gamma, dx, lddx, partial,
                        (long long)rows, C, CP_out);
-  }
   return srk_check_launch("rowln_bwd");
 }
 
