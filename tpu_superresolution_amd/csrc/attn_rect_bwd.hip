@@ -21,7 +21,12 @@
 
 namespace {
 
-constexpr int RP = 40;      // LDS row pitch (elements) of the [rows][32] tiles (as attn256.hip)
+// [rows][32] bf16 tiles without padding, the four 16-byte chunks of a row XOR-swizzled (the scheme of attn256_bwd.hip's self-attention
+// form): conflict-free for the row-per-lane fragment reads and for the transposing reads, and 4 x 256 x 64 B + statistics = 68 KB per
+// workgroup, so that TWO workgroups share a CU (the 40-element pitch needed 86 KB: one workgroup, one wave per SIMD).
+constexpr int RP = 32;
+__device__ __forceinline__ int tfs(int r) { return ((((r >> 2) ^ (r >> 3)) & 1) << 1) | (((r >> 3) ^ (r >> 1)) & 1); }
+__device__ __forceinline__ int chunk_off(int r, int c) { return r * 32 + ((c ^ tfs(r)) << 3); }      // element offset of 16-byte chunk c of row r
 
 struct RectBwdParams {
   const bf16_t* qkv;    // [T][ldq]
@@ -43,13 +48,19 @@ __device__ __forceinline__ bf16x8_t r_cat4(bf16x4_t lo, bf16x4_t hi) {
   return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 // transposed fragment in accumulator k order (slots (g, jj): rows k0 + 4 g + jj, jj < 4, and k0 + 16 + 4 g + jj - 4)
-__device__ __forceinline__ bf16x8_t r_tr_acc(const bf16_t* tile, int k0, int c0, int lane) {
-  const int g = lane >> 4;
-  return r_cat4(lds_tr_read(tr_addr(tile, RP, k0 + 4 * g, c0, lane)), lds_tr_read(tr_addr(tile, RP, k0 + 16 + 4 * g, c0, lane)));
+// k0 is a multiple of 32: the swizzle of rows k0 + 4 g + (ll >> 2) (+ 16) depends on the lane only -> `tro` = the lane's element offset
+// inside a 32-row block for c0 = 0 (tr_lane_off), c0 = 16 flips chunk bit 1
+__device__ __forceinline__ int tr_lane_off(int lane, int c0) {
+  const int ll = lane & 15, g = lane >> 4;
+  const int ra = 4 * g + (ll >> 2);
+  return chunk_off(ra, (c0 >> 3) + ((ll & 3) >> 1)) + ((ll & 1) << 2);
+}
+__device__ __forceinline__ bf16x8_t r_tr_acc(const bf16_t* tile, int k0, int tro) {
+  return r_cat4(lds_tr_read(tile + k0 * 32 + tro), lds_tr_read(tile + (k0 + 16) * 32 + tro));
 }
 
 template <int QT>        // 16-query tiles per wave: 4 (256-token windows) or 2 (128-token windows)
-__global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwdParams p) {
+__global__ __launch_bounds__(256, 2) void win_rect_attn_bwd_kernel(const RectBwdParams p) {
   constexpr int NQ = 64 * QT, NT = NQ / 16;
   constexpr float L2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -60,6 +71,8 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
   float* stats = reinterpret_cast<float*>(Os + NQ * RP);   // [NQ][4]: max * log2e, 1 / sum, rowsum(P dP)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
+  const int fro = r16 * 32 + ((g ^ tfs(r16)) << 3);           // fragment read of row 16 x + r16, chunk g: + 16 x * 32
+  const int tro[2] = {tr_lane_off(lane, 0), tr_lane_off(lane, 16)};
   const int h = blockIdx.x % p.nH;
   const int wflat = blockIdx.x / p.nH;
   const int nW = p.nWh * p.nWw;
@@ -96,10 +109,10 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<uint4*>(Qs + kk * RP + 8 * c) = qv[c];
-      *reinterpret_cast<uint4*>(Ks + kk * RP + 8 * c) = kv[c];
-      *reinterpret_cast<uint4*>(Vs + kk * RP + 8 * c) = vv[c];
-      *reinterpret_cast<uint4*>(Os + kk * RP + 8 * c) = ov[c];
+      *reinterpret_cast<uint4*>(Qs + chunk_off(kk, c)) = qv[c];
+      *reinterpret_cast<uint4*>(Ks + chunk_off(kk, c)) = kv[c];
+      *reinterpret_cast<uint4*>(Vs + chunk_off(kk, c)) = vv[c];
+      *reinterpret_cast<uint4*>(Os + chunk_off(kk, c)) = ov[c];
     }
   }
   __syncthreads();
@@ -119,13 +132,13 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
   for (int qt = 0; qt < QT; ++qt) {
     const int ql = wave * (16 * QT) + qt * 16 + r16;
     const int qlab = need_mask ? label(ql) : 0;
-    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + ql * RP + 8 * g);
-    const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Os + ql * RP + 8 * g);
+    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(Qs + (ql - r16) * 32 + fro);
+    const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Os + (ql - r16) * 32 + fro);
     f32x4_t s[NT], dp[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (16 * j + r16) * RP + 8 * g);
-      const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + (16 * j + r16) * RP + 8 * g);
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + 16 * j * 32 + fro);
+      const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + 16 * j * 32 + fro);
       s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
       }
       const bf16x8_t dsf = __builtin_bit_cast(bf16x8_t, make_uint4(lohi[0].x, lohi[0].y, lohi[1].x, lohi[1].y));
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) aq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r_tr_acc(Ks, 32 * jj, 16 * dt, lane), dsf, aq[dt], 0, 0, 0);
+      for (int dt = 0; dt < 2; ++dt) aq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r_tr_acc(Ks, 32 * jj, tro[dt]), dsf, aq[dt], 0, 0, 0);
     }
     const long long qt_tok = token(ql);
     if (qt_tok >= 0) {
@@ -203,8 +216,8 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
   for (int j = wave; j < NT; j += 4) {
     const int kl = 16 * j + r16;
     const int klab = need_mask ? label(kl) : 0;
-    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + kl * RP + 8 * g);
-    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + kl * RP + 8 * g);
+    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (kl - r16) * 32 + fro);
+    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + (kl - r16) * 32 + fro);
     f32x4_t av[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     f32x4_t ak[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 2
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * qp + u;
-        const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + (16 * qt + r16) * RP + 8 * g);
-        const bf16x8_t oa = *reinterpret_cast<const bf16x8_t*>(Os + (16 * qt + r16) * RP + 8 * g);
+        const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + 16 * qt * 32 + fro);
+        const bf16x8_t oa = *reinterpret_cast<const bf16x8_t*>(Os + 16 * qt * 32 + fro);
         // sa[e] = q . k of (query 16 qt + 4 g + e, key kl);  da[e] = dO . v of the same pair
         const f32x4_t sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const f32x4_t da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, vf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -235,8 +248,8 @@ __global__ __launch_bounds__(256, 1) void win_rect_attn_bwd_kernel(const RectBwd
       const bf16x8_t dfb = __builtin_bit_cast(bf16x8_t, make_uint4(dl2[0].x, dl2[0].y, dl2[1].x, dl2[1].y));
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r_tr_acc(Os, 32 * qp, 16 * dt, lane), pfb, av[dt], 0, 0, 0);
-        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r_tr_acc(Qs, 32 * qp, 16 * dt, lane), dfb, ak[dt], 0, 0, 0);
+        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r_tr_acc(Os, 32 * qp, tro[dt]), pfb, av[dt], 0, 0, 0);
+        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r_tr_acc(Qs, 32 * qp, tro[dt]), dfb, ak[dt], 0, 0, 0);
       }
     }
     const long long t = token(kl);
