@@ -360,6 +360,14 @@ size_t srk_channel_attention_workspace(int B, int N, int num_heads);
 int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* temperature, void* workspace, uint16_t* out, int ldo, int B,
                               int N, int num_heads, int head_dim, srk_stream_t stream);
 
+/* Backward of Mlp + residual + the LayerNorm in front of it as ONE kernel (autograd of hat_arch.py:86-92 + :324 / network_swinir.py:25-28
+ * + :277): d u = (g W2) * gelu'(u) -> du_out, d xn = d u W1, LayerNorm backward through (ln_x, mean, rstd, gamma): gx += d x in place
+ * (fp32), gxb = bf16(gx * rowscale[row / rows_per_sample]) (or null), d_gamma / d_beta ACCUMULATED.  Layouts as srk_mlp_fused_fwd with
+ * the weights transposed: w2t [384][192], w1t [192][384]; C = 180, M % 64 == 0, M >= 64 * #CUs, else SRK_E_UNSUPPORTED. */
+int srk_mlp_fused_bwd(const uint16_t* g, const uint16_t* w2t, const uint16_t* u, uint16_t* du_out, const uint16_t* w1t, const float* ln_x,
+                      const float* ln_mean, const float* ln_rstd, const float* ln_gamma, float* gx, uint16_t* gxb, const float* rowscale,
+                      int rows_per_sample, float* d_gamma, float* d_beta, int C, int M, srk_stream_t stream);
+
 /* ---- DAT training pieces (csrc/dat_train.hip, csrc/attn_rect_bwd.hip) -----------------------------------------------------------
  * Token-sized work and token reductions only: the per-channel / per-sample functions in between (train-mode BatchNorm coefficients
  * dat_arch.py:301-313 / :464-476, channel_interaction on the pooled [B][C] vector, the d x d channel-attention matrices :497-503,

@@ -295,3 +295,37 @@ def test_hat_train_step_with_drop_path_runs_and_learns():
         opt.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_hat_width_180_backward_fused_mlp_kernel_vs_separate_kernels():
+    """At the HAT-SRx4 width with >= 64 * #CUs tokens the MLP half of every block's backward runs as ONE kernel (srk_mlp_fused_bwd: fc2 dgrad *
+    GELU' -> fc1 dgrad -> norm2 backward, bf16 copy scaled by the DropPath factor): same gradients as the separate GEMMs + LayerNorm
+    backward (option mlp_bwd_fused = 0), DropPath factors identical in both runs."""
+    import tpu_superresolution_amd as T
+    from tpu_superresolution_amd._lib import check, lib
+    cfg = HO.HATConfig(**{**HO.HATConfig.sr_x4().__dict__, "depths": (2,), "num_heads": (6,)})
+    sd = HO.random_state_dict(cfg, seed=3, scale=1.0)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand(4, 3, 64, 64, generator=gen).cuda()          # 16 384 tokens
+    t = torch.rand(4, 3, 256, 256, generator=gen).cuda()
+    res = {}
+    try:
+        for on in (1, 0):
+            check(lib().srk_set_option(b"mlp_bwd_fused", on))
+            m = T.HAT(drop_path_rate=0.2, **cfg.kwargs())
+            m.load_state_dict(sd, strict=True)
+            m = m.cuda().train()
+            torch.manual_seed(5)
+            torch.cuda.manual_seed(5)
+            out = m(x)
+            torch.nn.functional.l1_loss(out, t).backward()
+            res[on] = (out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
+    finally:
+        check(lib().srk_set_option(b"mlp_bwd_fused", 1))
+    assert torch.equal(res[1][0], res[0][0])
+    worst = 0.0
+    for n in res[0][1]:
+        rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel <= 2e-3, (n, rel)         # d u leaves the fused kernel's LDS in bf16 exactly as the separate path stores it; fp32 atomics differ in order
+    print("worst relative gradient difference", worst)

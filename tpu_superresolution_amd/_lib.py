@@ -130,6 +130,7 @@ _SIGNATURES = {
     "srk_dual_gate_combine": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_channel_attention_workspace": (_sz, [_i, _i, _i]),
     "srk_channel_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_mlp_fused_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "srk_win_attention_bwd_padded_scratch": (_sz, [_i, _i, _i, _i, _i, _i]),
     "srk_win_attention_bwd_padded": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "srk_chan_stats_chunks": (_i64, [_i64]),

@@ -290,4 +290,28 @@ int srk_mlp_fused_fwd_train(const uint16_t* xn, const uint16_t* w1, const float*
   return rc;
 }
 
+// Backward of Mlp + residual + the LayerNorm in front of it as ONE kernel (csrc/gemm_stream.hip: mlp_fused_bwd_kernel), for the
+// host-orchestrated backward passes: d u = (g W2) * gelu'(u) (written: the fc1 weight gradient reads it), d xn = d u W1, LayerNorm
+// backward of d xn through (ln_x, mean, rstd, gamma): gx += d x (fp32 gradient stream, in place), gxb = bf16(gx * rowscale[sample]),
+// d_gamma / d_beta ACCUMULATED.  g bf16 [M][192], w2t bf16 [384][192] (= fc2.weight^T packed), u bf16 [M][384], w1t bf16 [192][384].
+int srk_mlp_fused_bwd(const uint16_t* g, const uint16_t* w2t, const uint16_t* u, uint16_t* du_out, const uint16_t* w1t, const float* ln_x,
+                      const float* ln_mean, const float* ln_rstd, const float* ln_gamma, float* gx, uint16_t* gxb, const float* rowscale,
+                      int rows_per_sample, float* d_gamma, float* d_beta, int C, int M, srk_stream_t stream) {
+  SRK_REQUIRE(g && w2t && u && du_out && w1t && ln_x && ln_mean && ln_rstd && ln_gamma && gx && d_gamma && d_beta, SRK_E_NULL,
+              "mlp_fused_bwd: null pointer");
+  GemmParams p = {};
+  p.A = g; p.lda = 192; p.Wt = w2t; p.K = 192; p.HP = 384; p.aux = u; p.u_out = du_out; p.W2 = w1t; p.M = M; p.N = 192; p.ldo = 192;
+  p.outf = gx; p.outb = gxb; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample;
+  p.ln_x = ln_x; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd; p.ln_gamma = ln_gamma; p.ln_dgamma = d_gamma; p.ln_dbeta = d_beta; p.ln_C = C;
+  p.ln_rows_window = 0; p.ln_stats_by_m = 0; p.ln_out_window = 0;
+  p.flops = 8.0 * M * 180.0 * 360.0;
+  const int rc = srk_launch_mlp_fused_bwd(p, (hipStream_t)stream);
+  if (rc == SRK_NOT_COVERED) {
+    srk_set_error("mlp_fused_bwd: shape not covered (needs C 180/192, hidden 360/384, M %% 64 == 0, M >= 64 * #CUs, rows_per_sample %% 64 == 0; "
+                  "got M=%d)", M);
+    return SRK_E_UNSUPPORTED;
+  }
+  return rc;
+}
+
 }  // extern "C"

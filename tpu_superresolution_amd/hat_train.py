@@ -343,6 +343,10 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
     ln_bwd(dxn, S["x_last"], S["meanf"], S["rstdf"], m.norm, gx, gxb, accumulate=False)
     segment_done()
 
+    opt = C.c_int()
+    check(L.srk_get_option(b"mlp_bwd_fused", C.byref(opt)))
+    fused_mlp_bwd_ok = (opt.value != 0 and CP == 192 and HP == 384 and T % 64 == 0 and HW % 64 == 0 and
+                        T >= 64 * torch.cuda.get_device_properties(dev).multi_processor_count)
     # ---------------- layers, last to first ----------------
     blocks = S["blocks"]
     pos = len(blocks)
@@ -364,13 +368,26 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             # ---- MLP half: x2 = x1 + f_mlp * fc2(gelu(fc1(norm2(x1)))) ----
             g_mlp = scaled(gxb2, bk["bidx"], 1) if hab else gxb2
             du = torch.empty(T, HP, **b16)
-            _gemm(st, _lib.LD_ROWS, _lib.EP_DGELU, g_mlp, PT[pre + "W2T"], T, HP, CP, lda=CP, aux=bk["u"], outb=du, ldo=HP)
+            g1b = torch.empty(T, CP, **b16)
+            g1b_scaled = False
+            if fused_mlp_bwd_ok:
+                # fc2 dgrad * GELU' -> fc1 dgrad -> norm2 backward in one kernel; the bf16 copy comes out already scaled by the attention
+                # branch's DropPath factor
+                dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+                rsc = drop[bk["bidx"], 0] if (hab and drop is not None) else None
+                check(L.srk_mlp_fused_bwd(g_mlp.data_ptr(), PT[pre + "W2T"].data_ptr(), bk["u"].data_ptr(), du.data_ptr(), PT[pre + "W1T"].data_ptr(),
+                                          bk["x1"].data_ptr(), bk["mean2"].data_ptr(), bk["rstd2"].data_ptr(), blk.norm2.weight.data_ptr(),
+                                          gx2.data_ptr(), g1b.data_ptr(), _ptr(rsc), HW, dg.data_ptr(), dbt.data_ptr(), C_, T, st))
+                G[pname(blk.norm2.weight)], G[pname(blk.norm2.bias)] = dg, dbt
+                g1b_scaled = True
+            else:
+                _gemm(st, _lib.LD_ROWS, _lib.EP_DGELU, g_mlp, PT[pre + "W2T"], T, HP, CP, lda=CP, aux=bk["u"], outb=du, ldo=HP)
             lin_wgrad(g_mlp, bk["h"], blk.mlp.fc2, CP, HP)
             lin_wgrad(du, bk["xn2"], blk.mlp.fc1, HP, CP)
-            dxn2 = torch.empty(T, CP, **b16)
-            _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, du, PT[pre + "W1T"], T, CP, HP, lda=HP, outb=dxn2)
-            g1b = torch.empty(T, CP, **b16)
-            ln_bwd(dxn2, bk["x1"], bk["mean2"], bk["rstd2"], blk.norm2, gx2, g1b, accumulate=True)      # gx2 = d x1 (fp32), g1b its bf16 copy
+            if not fused_mlp_bwd_ok:
+                dxn2 = torch.empty(T, CP, **b16)
+                _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, du, PT[pre + "W1T"], T, CP, HP, lda=HP, outb=dxn2)
+                ln_bwd(dxn2, bk["x1"], bk["mean2"], bk["rstd2"], blk.norm2, gx2, g1b, accumulate=True)      # gx2 = d x1 (fp32), g1b its bf16 copy
             dxc = None
             if hab:
                 # ---- CAB: x1 += conv2(gelu(conv1(xn1))) * gate ----
@@ -396,7 +413,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                 _gemm(st, _lib.LD_CONV3, _lib.EP_F32_BF16, du1, PT[pre + "Wc0T"], T, CP, 9 * 64, conv=(B, H, W, 64), outf=dxc)
             # ---- attention half: x1 = x + f_attn * proj(attention(qkv(norm1(x)))) ----
             attn_mod = blk.attn if hab else blk
-            g_att = scaled(g1b, bk["bidx"], 0) if hab else g1b
+            g_att = scaled(g1b, bk["bidx"], 0) if (hab and not g1b_scaled) else g1b
             dao = torch.empty(T, CA, **b16)
             _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, g_att, PT[pre + "WprojT"], T, CA, CP, lda=CP, outb=dao, ldo=CA)
             lin_wgrad(g_att, bk["ao"], attn_mod.proj, CP, CA, col_map=hm)
