@@ -220,6 +220,9 @@ enum { SRK_EP_BF16 = 0,       /* outb = bf16(v + bias) */
        SRK_EP_DGELU = 5,      /* outb = bf16(v * gelu'(aux))            (backward through an exact-erf GELU; aux = pre-activation) */
        SRK_EP_DLRELU = 11,    /* outb = bf16(v * (aux > 0 ? 1 : scale)) (backward through LeakyReLU; aux = its output) */
        SRK_EP_F32_BF16 = 12,  /* outf = v (fp32) [+ outb = bf16(v)] */
+       SRK_EP_LNBWD = 13,     /* v = gradient of a LayerNorm OUTPUT row (N = the padded width, <= 192): LayerNorm backward through (ln_x, ln_mean,
+                                 ln_rstd, ln_gamma) fused in: outf += d x in place (fp32 gradient stream), outb = bf16(outf * rowscale) or null,
+                                 ln_dgamma / ln_dbeta ACCUMULATED.  A dgrad GEMM whose consumer is a LayerNorm backward (no bias) */
        SRK_EP_MLP_FUSED = 100 /* (reserved; see srk_mlp_fused_fwd) */ };
 typedef struct {
   int loader, epilogue;
@@ -236,6 +239,7 @@ typedef struct {
   float inv_range; float mean[4]; int Cimg, Hc, Wc;     /* SRK_EP_IMG */
   void* xn_out; float* xn_mean; float* xn_rstd; const float* xn_gamma; const float* xn_beta; int xn_C;   /* SRK_EP_RES fused LayerNorm */
   const float* rowscale; int rows_per_sample;   /* SRK_EP_RES: outf = res + rowscale[m / rows_per_sample] * (v + bias)  (DropPath factor per sample) or null */
+  const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_gamma; float* ln_dgamma; float* ln_dbeta; int ln_C;   /* SRK_EP_LNBWD */
 } srk_gemm_args;
 int srk_gemm_ex(const srk_gemm_args* args, srk_stream_t stream);
 /* Mlp.forward + residual (+ next LayerNorm) in one kernel (csrc/gemm_stream.hip): out = res + gelu(xn W1^T + b1) W2^T + b2.

@@ -43,12 +43,14 @@ class GemmArgs(C.Structure):
                 ("outb2", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("ldo", C.c_int), ("scale", C.c_float),
                 ("inv_range", C.c_float), ("mean", C.c_float * 4), ("Cimg", C.c_int), ("Hc", C.c_int), ("Wc", C.c_int),
                 ("xn_out", C.c_void_p), ("xn_mean", C.c_void_p), ("xn_rstd", C.c_void_p), ("xn_gamma", C.c_void_p),
-                ("xn_beta", C.c_void_p), ("xn_C", C.c_int), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int)]
+                ("xn_beta", C.c_void_p), ("xn_C", C.c_int), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
+                ("ln_x", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_dgamma", C.c_void_p),
+                ("ln_dbeta", C.c_void_p), ("ln_C", C.c_int)]
 
 
 LD_ROWS, LD_CONV3, LD_CONV3_PS = 0, 1, 2
 EP_BF16, EP_GELU, EP_RES, EP_LRELU, EP_PS, EP_IMG, EP_PS_IMG, EP_RES_BF16 = 0, 3, 4, 6, 7, 8, 9, 10
-EP_DGELU, EP_DLRELU, EP_F32_BF16 = 5, 11, 12
+EP_DGELU, EP_DLRELU, EP_F32_BF16, EP_LNBWD = 5, 11, 12, 13
 
 UPSAMPLER_PIXELSHUFFLE = 1
 UPSAMPLER_PIXELSHUFFLEDIRECT = 2

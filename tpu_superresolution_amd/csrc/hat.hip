@@ -228,8 +228,8 @@ int srk_gemm_ex(const srk_gemm_args* a, srk_stream_t stream) {
   p.xn_out = static_cast<bf16_t*>(a->xn_out); p.xn_mean = a->xn_mean; p.xn_rstd = a->xn_rstd; p.xn_gamma = a->xn_gamma;
   p.xn_beta = a->xn_beta; p.xn_C = a->xn_C;
   p.rowscale = a->rowscale; p.rows_per_sample = a->rows_per_sample;
-  SRK_REQUIRE(a->rowscale == nullptr || (a->epilogue == SRK_EP_RES && a->rows_per_sample > 0), SRK_E_SHAPE,
-              "gemm_ex: rowscale goes with SRK_EP_RES and rows_per_sample > 0");
+  SRK_REQUIRE(a->rowscale == nullptr || ((a->epilogue == SRK_EP_RES || a->epilogue == SRK_EP_LNBWD) && a->rows_per_sample > 0), SRK_E_SHAPE,
+              "gemm_ex: rowscale goes with SRK_EP_RES / SRK_EP_LNBWD and rows_per_sample > 0");
   p.flops = 2.0 * a->M * (double)a->N * a->K;
   switch (a->epilogue) {
     case SRK_EP_BF16: case SRK_EP_GELU: case SRK_EP_RES: case SRK_EP_LRELU: case SRK_EP_PS: case SRK_EP_IMG: case SRK_EP_PS_IMG: case SRK_EP_RES_BF16:
@@ -239,6 +239,14 @@ int srk_gemm_ex(const srk_gemm_args* a, srk_stream_t stream) {
       break;
     case SRK_EP_F32_BF16:
       SRK_REQUIRE(a->outf != nullptr, SRK_E_NULL, "gemm_ex: SRK_EP_F32_BF16 needs outf");
+      break;
+    case SRK_EP_LNBWD:
+      SRK_REQUIRE(a->loader == SRK_LD_ROWS && a->outf && a->ln_x && a->ln_mean && a->ln_rstd && a->ln_gamma && a->ln_dgamma && a->ln_dbeta, SRK_E_NULL,
+                  "gemm_ex: SRK_EP_LNBWD needs LD_ROWS, outf and the LayerNorm operands");
+      SRK_REQUIRE((a->N == 64 || a->N == 128 || a->N == 192) && a->ln_C > 0 && a->ln_C <= a->N && a->ldo == a->N && a->bias == nullptr, SRK_E_SHAPE,
+                  "gemm_ex: SRK_EP_LNBWD needs N = 64 / 128 / 192 = ldo (one tile holds a whole row), no bias");
+      p.ln_x = a->ln_x; p.ln_mean = a->ln_mean; p.ln_rstd = a->ln_rstd; p.ln_gamma = a->ln_gamma; p.ln_dgamma = a->ln_dgamma;
+      p.ln_dbeta = a->ln_dbeta; p.ln_C = a->ln_C;
       break;
     default:
       srk_set_error("gemm_ex: epilogue %d is not exposed", a->epilogue);

@@ -564,7 +564,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _gemm(st, loader, ep, A, W, M, N, K, *, lda=0, conv=None, bias=None, outf=None, outb=None, outb2=None, res=None, ldo=0, scale=0.0,
-          r=0, Cs=0, img=None, xn=None, aux=None, rowscale=None, rows_per_sample=0):
+          r=0, Cs=0, img=None, xn=None, aux=None, rowscale=None, rows_per_sample=0, ln=None):
     a = GemmArgs()
     a.loader, a.epilogue = loader, ep
     a.A, a.lda, a.W, a.M, a.N, a.K = _ptr(A), lda, _ptr(W), M, N, K
@@ -581,6 +581,9 @@ def _gemm(st, loader, ep, A, W, M, N, K, *, lda=0, conv=None, bias=None, outf=No
     if xn is not None:
         a.xn_out, a.xn_mean, a.xn_rstd, a.xn_gamma, a.xn_beta, a.xn_C = (_ptr(xn["out"]), _ptr(xn["mean"]), _ptr(xn["rstd"]),
                                                                        _ptr(xn["gamma"]), _ptr(xn["beta"]), xn["C"])
+    if ln is not None:      # EP_LNBWD: LayerNorm backward fused into the dgrad's epilogue
+        a.ln_x, a.ln_mean, a.ln_rstd, a.ln_gamma = _ptr(ln["x"]), _ptr(ln["mean"]), _ptr(ln["rstd"]), _ptr(ln["gamma"])
+        a.ln_dgamma, a.ln_dbeta, a.ln_C = _ptr(ln["dgamma"]), _ptr(ln["dbeta"]), ln["C"]
     check(lib().srk_gemm_ex(C.byref(a), st))
 
 

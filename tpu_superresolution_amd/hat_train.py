@@ -432,9 +432,15 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             dxn1 = torch.empty(T, CP, **b16)
             if dxc is not None:
                 _gemm(st, _lib.LD_ROWS, _lib.EP_RES_BF16, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, res=dxc, outb=dxn1)
+                ln_bwd(dxn1, bk["x_in"], bk["mean1"], bk["rstd1"], blk.norm1, gx2, gxb2, accumulate=True)
+            elif CP in (64, 128, 192):      # OCAB: qkv dgrad with the norm1 backward in its epilogue
+                dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+                _gemm(st, _lib.LD_ROWS, _lib.EP_LNBWD, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, outf=gx2, outb=gxb2, ldo=CP,
+                      ln=dict(x=bk["x_in"], mean=bk["mean1"], rstd=bk["rstd1"], gamma=blk.norm1.weight, dgamma=dg, dbeta=dbt, C=C_))
+                G[pname(blk.norm1.weight)], G[pname(blk.norm1.bias)] = dg, dbt
             else:
                 _gemm(st, _lib.LD_ROWS, _lib.EP_BF16, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, outb=dxn1)
-            ln_bwd(dxn1, bk["x_in"], bk["mean1"], bk["rstd1"], blk.norm1, gx2, gxb2, accumulate=True)
+                ln_bwd(dxn1, bk["x_in"], bk["mean1"], bk["rstd1"], blk.norm1, gx2, gxb2, accumulate=True)
         # layer skip: d(layer input) = d(body input) + d(layer output)
         check(L.srk_add_f32_bf16(gx.data_ptr(), gx2.data_ptr(), gxb.data_ptr(), T * CP, st))
         segment_done()
