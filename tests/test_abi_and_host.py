@@ -132,3 +132,76 @@ def test_options_are_per_thread_and_per_plan():
     with pytest.raises(_lib.SrkUnsupported, match="unknown option"):
         plan.set_option("no_such_option", 1)
     assert plan.get_option("gemm_stream_bm") == (32, True)
+
+
+def test_batched_weight_packing_equals_one_tensor_at_a_time():
+    """hat_arch.batched_pack: the packed (bf16 / padded / permuted / transposed) weights of HAT, DAT (inference and training subsets) and
+    SwinIR window-16 built by one stack + scatter + cast per weight kind are bit-identical to the tensor-by-tensor pack (pure torch: runs
+    on the CPU)."""
+    import torch
+    import tpu_superresolution_amd as T
+    from tpu_superresolution_amd import dat_arch, dat_train, hat_arch as ha, hat_train, swinir_w16
+
+    class Eager:                      # a context whose helpers run eagerly (no active packer)
+        def __enter__(self):
+            class R:
+                def resolve(self, P):
+                    pass
+            return R()
+
+        def __exit__(self, *a):
+            pass
+
+    def both(fn):
+        a = fn()
+        mods = (ha, dat_arch, swinir_w16)
+        real = ha.batched_pack
+        for mod in mods:
+            mod.batched_pack = Eager
+        try:
+            b = fn()
+        finally:
+            for mod in mods:
+                mod.batched_pack = real
+        assert a.keys() == b.keys()
+        for k in a:
+            assert isinstance(a[k], torch.Tensor), (k, type(a[k]))
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) and a[k].is_contiguous(), k
+        return len(a)
+
+    dev = torch.device("cpu")
+    torch.manual_seed(0)
+    m = T.HAT(upscale=2, in_chans=3, img_size=32, window_size=16, compress_ratio=3, squeeze_factor=6, conv_scale=0.01, overlap_ratio=0.5,
+              img_range=1.0, depths=[2, 2], embed_dim=24, num_heads=[2, 2], mlp_ratio=2, upsampler="pixelshuffle", resi_connection="1conv")
+    d = T.DAT(img_size=32, in_chans=3, embed_dim=48, split_size=[8, 32], depth=[3, 2], num_heads=[4, 4], expansion_factor=2.0, upscale=2, img_range=1.0)
+    s = T.SwinIR(img_size=32, in_chans=3, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=16, mlp_ratio=2, img_range=1.0, upscale=2,
+                 upsampler="pixelshuffle")
+
+    def reset(obj, *names):
+        for n in names:
+            setattr(obj, n, None)
+
+    def hat_p():
+        reset(m, "_packed")
+        return dict(m._pack(dev))
+
+    def hat_pt():
+        reset(m, "_packedT")
+        return dict(hat_train.pack_transposed(m, dev))
+
+    def dat_p(train):
+        def f():
+            reset(d, "_packed")
+            return dict(d._pack(dev, train))
+        return f
+
+    def dat_pt():
+        reset(d, "_packedT")
+        return dict(dat_train.pack_train(d, dev))
+
+    def w16_p():
+        reset(s, "_w16_packed")
+        return dict(swinir_w16.pack(s, dev))
+
+    assert both(hat_p) == 93 and both(hat_pt) == 37 and both(dat_p(False)) == 131 and both(dat_p(True)) == 73 and both(dat_pt) == 48
+    assert both(w16_p) == 45

@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import Dict, List, Optional
 
 import torch
@@ -240,20 +241,23 @@ class _Packer:
                 P[name] = done[v.group][v.index]
 
 
-_ACTIVE: Optional[_Packer] = None
+_TLS = threading.local()        # the active packer is per thread (two threads may pack two models at once)
+
+
+def _active() -> Optional[_Packer]:
+    return getattr(_TLS, "packer", None)
 
 
 class batched_pack:
     """with batched_pack() as pk: ... P[name] = _pack_linear(...) ...; pk.resolve(P)"""
 
     def __enter__(self):
-        global _ACTIVE
-        self.prev, _ACTIVE = _ACTIVE, _Packer()
-        return _ACTIVE
+        self.prev = _active()
+        _TLS.packer = _Packer()
+        return _TLS.packer
 
     def __exit__(self, *exc):
-        global _ACTIVE
-        _ACTIVE = self.prev
+        _TLS.packer = self.prev
 
 
 def _many_linear(ws, NP, KP, row_map, col_map):
@@ -294,30 +298,34 @@ _PACK_MANY = {"linear": _many_linear, "vec": _many_vec, "conv": _many_conv, "con
 
 def _pack_linear(w: torch.Tensor, NP: int, KP: int, row_map=None, col_map=None) -> torch.Tensor:
     """fp32 [N][K] -> bf16 [NP][KP], rows / columns scattered through the given index maps (zero elsewhere)."""
-    if _ACTIVE is not None:
-        return _ACTIVE.add("linear", w, (NP, KP), (row_map, col_map))
+    pk = _active()
+    if pk is not None:
+        return pk.add("linear", w, (NP, KP), (row_map, col_map))
     return _many_linear(w.float()[None], NP, KP, row_map, col_map)[0].contiguous()
 
 
 def _pack_vec(b: Optional[torch.Tensor], NP: int, row_map=None, device=None) -> torch.Tensor:
     if b is None:
         return torch.zeros(NP, dtype=torch.float32, device=device)
-    if _ACTIVE is not None:
-        return _ACTIVE.add("vec", b, (NP,), (row_map,))
+    pk = _active()
+    if pk is not None:
+        return pk.add("vec", b, (NP,), (row_map,))
     return _many_vec(b.float()[None], NP, row_map)[0]
 
 
 def _pack_conv(w: torch.Tensor, NP: int, CinP: int, row_map=None) -> torch.Tensor:
     """[Cout][Cin][3][3] -> bf16 [NP][9 * CinP], K tap-major: k = (3 ky + kx) * CinP + ci."""
-    if _ACTIVE is not None:
-        return _ACTIVE.add("conv", w, (NP, CinP), (row_map,))
+    pk = _active()
+    if pk is not None:
+        return pk.add("conv", w, (NP, CinP), (row_map,))
     return _many_conv(w.float()[None], NP, CinP, row_map)[0].contiguous()
 
 
 def _pack_conv_T(w: torch.Tensor, NP: int, CoutP: int, col_map=None) -> torch.Tensor:
     """[Cout][Cin][3][3] -> bf16 [NP (input channels)][9 * CoutP]: the dgrad's weight, taps flipped, K = (tap, output channel)."""
-    if _ACTIVE is not None:
-        return _ACTIVE.add("convT", w, (NP, CoutP), (col_map,))
+    pk = _active()
+    if pk is not None:
+        return pk.add("convT", w, (NP, CoutP), (col_map,))
     return _many_conv_T(w.float()[None], NP, CoutP, col_map)[0].contiguous()
 
 
