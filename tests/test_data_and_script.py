@@ -103,3 +103,32 @@ def test_finetune_script_with_the_training_set_on_the_device(tmp_path, capsys, m
     assert "[gpu_data] 6 pairs" in out and "[X4] epoch 002/2" in out and "[done] best_val_loss=" in out
     ck = torch.load(tmp_path / "bestpsnr_swinir_finetune_X4.pt", map_location="cpu", weights_only=False)
     assert set(ck) >= {"model", "epoch", "best_val_psnr", "val_loss", "args"} and ck["args"]["gpu_data"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["hat", "dat"])
+def test_train_and_evaluate_scripts_with_the_transformer_archs(arch, tmp_path, capsys, monkeypatch):
+    """train.py / evaluate.py (the reference's entry points, 19 + 10 flags) with the additive --arch hat | dat: one epoch of training on a
+    synthetic tree through the HIP training path (DAT: train-mode BatchNorm), the checkpoint it writes evaluated by evaluate.py."""
+    from tpu_superresolution_amd import evaluate, train
+    root = str(tmp_path / "data")
+    make_dataset(root, n_train=4, n_valid=2, lr=48, scale=2)
+    hr_dir = os.path.join(root, "shuffled2D", "shuffled2D_test_HR")
+    lr_dir = os.path.join(root, "shuffled2D", "shuffled2D_test_LR_default_X2")
+    os.makedirs(hr_dir)
+    os.makedirs(lr_dir)
+    rng = np.random.RandomState(1)
+    for i in range(2):
+        hr = (rng.rand(96, 96) * 255).astype(np.uint8)
+        Image.fromarray(hr, "L").save(os.path.join(hr_dir, f"{i:04d}.png"))
+        Image.fromarray(hr, "L").resize((48, 48), Image.BICUBIC).save(os.path.join(lr_dir, f"{i:04d}x2.png"))
+    monkeypatch.chdir(tmp_path)
+    out = train.main(["--data_root", root, "--scale", "X2", "--epochs", "1", "--batch_size", "2", "--patch_size", "32", "--loss", "l1", "--lr", "1e-4",
+                      "--workers", "0", "--arch", arch, "--device", "cuda"])
+    text = capsys.readouterr().out
+    assert "[X2] epoch 1: train_loss" in text and np.isfinite(out["best"])
+    ck = tmp_path / "best_X2.pt"
+    assert ck.exists()
+    res = evaluate.main(["--scale", "X2", "--data_root", root, "--ckpt", str(ck), "--batch_size", "1", "--save_dir", str(tmp_path / "p"), "--save_n", "1",
+                         "--arch", arch, "--device", "cuda"])
+    assert np.isfinite(res["psnr"]) and 0 < res["ssim"] <= 1 and res["n"] == 2

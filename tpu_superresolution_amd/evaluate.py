@@ -10,7 +10,7 @@ non-finite guard (:172-178), optional bilinear resize to the HR size (:181-184),
 by --save_n (:199-225) -> summary (:229-234).
 
 BASELINE config 1 runs this on the CPU with stock torch operators (MS_ResUNet has no kernel in scope).
-Additive: ``--arch swinir`` evaluates the MI355X SwinIR path (finetune_swinir.py model, RGB un-upscaled LR input, needs a
+Additive: ``--arch swinir | hat | dat`` evaluates the MI355X SwinIR / HAT / DAT path (finetune_swinir.py model, RGB un-upscaled LR input, needs a
 GPU + libsrk); ``main(argv)`` is callable from tests.  SSIM is ``metrics.ssim`` (restated, parity unpinned).
 """
 from __future__ import annotations
@@ -66,15 +66,15 @@ def main(argv=None):
     ap.add_argument("--save_start", type=int, default=0, help="first index of the periodic saving (for save_every)")
     ap.add_argument("--save_indices", type=str, default="",
                     help="explicit comma-separated indices, e.g. '0,100,200'; takes priority over save_every")
-    ap.add_argument("--arch", type=str, choices=["ms_resunet", "swinir"], default="ms_resunet")       # additive
+    ap.add_argument("--arch", type=str, choices=["ms_resunet", "swinir", "hat", "dat"], default="ms_resunet")       # additive
     ap.add_argument("--device", type=str, default=None, help="additive: force 'cpu' / 'cuda' (default: cuda if available)")
     args = ap.parse_args(argv)
 
     device = torch.device(args.device) if args.device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     print("[device]", device, torch.cuda.get_device_name(0) if device.type == "cuda" else "-")
-    swin = args.arch == "swinir"
+    swin = args.arch in ("swinir", "hat", "dat")
     if swin and device.type != "cuda":
-        raise SystemExit("--arch swinir runs on the MI355X HIP path only (no CPU fallback)")
+        raise SystemExit(f"--arch {args.arch} runs on the MI355X HIP path only (no CPU fallback)")
     scale_int = 2 if args.scale.upper() == "X2" else 4
 
     if swin:
@@ -111,8 +111,8 @@ def main(argv=None):
     print(f"[baseline] Bicubic PSNR: {sum(ps) / len(ps):.2f} dB | SSIM: {sum(ss) / len(ss):.4f}")
 
     if swin:
-        from .finetune_swinir import build_model
-        model = build_model(scale_int, drop_path_rate=0.0)
+        from .finetune_swinir import build_sr_model
+        model = build_sr_model(args.arch, scale_int, drop_path_rate=0.0)
     else:
         model = MS_ResUNet()
     state, msg = _load_state(args.ckpt)

@@ -137,6 +137,24 @@ def build_model(scale_int: int, drop_path_rate: float = 0.1) -> SwinIR:
                   drop_path_rate=drop_path_rate)
 
 
+def build_sr_model(arch: str, scale_int: int, drop_path_rate: float = 0.1):
+    """The transformer SR models of modules/ at their published x2 / x4 hyper-parameters, on the HIP path: 'swinir'
+    (finetune_swinir.py:269-281), 'hat' (HAT-SRx4 configuration of hat_arch.py's constructor defaults: window 16, overlap 0.5, CAB),
+    'dat' (official DAT configuration: split [8, 32], expansion 4; dat_arch.py:721-741).  Used by train.py / evaluate.py --arch."""
+    if arch == "swinir":
+        return build_model(scale_int, drop_path_rate)
+    if arch == "hat":
+        from .hat_arch import HAT
+        return HAT(upscale=scale_int, in_chans=3, img_size=64, window_size=16, compress_ratio=3, squeeze_factor=30, conv_scale=0.01,
+                   overlap_ratio=0.5, img_range=1.0, depths=[6] * 6, embed_dim=180, num_heads=[6] * 6, mlp_ratio=2,
+                   upsampler="pixelshuffle", resi_connection="1conv", drop_path_rate=drop_path_rate)
+    if arch == "dat":
+        from .dat_arch import DAT
+        return DAT(upscale=scale_int, in_chans=3, img_size=64, img_range=1.0, depth=[6] * 6, embed_dim=180, num_heads=[6] * 6,
+                   expansion_factor=4, resi_connection="1conv", split_size=[8, 32], upsampler="pixelshuffle", drop_path_rate=drop_path_rate)
+    raise ValueError(f"unknown arch {arch!r}")
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--data_root", type=str, required=True)

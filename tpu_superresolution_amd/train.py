@@ -14,7 +14,7 @@ validate (nan_to_num, loss, PSNR :46-56, SSIM), epoch print (:375-381), ETA prin
 (:403-419) -> total-time prints.
 
 MS_ResUNet runs on stock torch operators (CPU, or the GPU through torch's ROCm operators): SURVEY 8 row a17 puts no
-kernel of it in scope.  Additive: ``--arch swinir`` trains the MI355X SwinIR path with this loop (RGB LR patches of
+kernel of it in scope.  Additive: ``--arch swinir | hat | dat`` trains the MI355X SwinIR / HAT / DAT path with this loop (RGB LR patches of
 ``--patch_size``, no autocast -- bf16 MFMA is inside the kernels -- torch AdamW on the flat-buffer views; the tuned loop
 for it is ``finetune_swinir.py``); ``main(argv)`` is callable from tests.  SSIM is ``metrics.ssim`` (restated from the
 published pytorch-msssim algorithm; parity unpinned).
@@ -177,7 +177,7 @@ def main(argv=None):
                     help="use the checkpoint as initialisation only (optimizer / scheduler are not restored)")
     ap.add_argument("--freeze_regex", type=str, default=None, help="regex over parameter names to freeze, e.g. 'inc|down'")
     ap.add_argument("--ft_lr", type=float, default=None, help="separate learning rate for fine-tuning (default: --lr)")
-    ap.add_argument("--arch", type=str, choices=["ms_resunet", "swinir"], default="ms_resunet")       # additive
+    ap.add_argument("--arch", type=str, choices=["ms_resunet", "swinir", "hat", "dat"], default="ms_resunet")       # additive
     ap.add_argument("--device", type=str, default=None, help="additive: force 'cpu' / 'cuda' (default: cuda if available)")
     args = ap.parse_args(argv)
 
@@ -189,9 +189,9 @@ def main(argv=None):
     print(f"[cfg] workers={args.workers}, pin={not args.no_pin}, persistent={not args.no_persistent}")
     device = torch.device(args.device) if args.device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     print("[device]", device, torch.cuda.get_device_name(0) if device.type == "cuda" else "-")
-    swin = args.arch == "swinir"
+    swin = args.arch in ("swinir", "hat", "dat")          # the transformer models of modules/ on the HIP path: RGB LR patches in, x scale out
     if swin and device.type != "cuda":
-        raise SystemExit("--arch swinir runs on the MI355X HIP path only (no CPU fallback)")
+        raise SystemExit(f"--arch {args.arch} runs on the MI355X HIP path only (no CPU fallback)")
     scale_int = 2 if args.scale.upper() == "X2" else 4
     pin = (not args.no_pin) and device.type == "cuda"
 
@@ -212,8 +212,8 @@ def main(argv=None):
     warmup_profile(train_loader, n_batches=3)
 
     if swin:
-        from .finetune_swinir import build_model
-        model = build_model(scale_int).to(device)
+        from .finetune_swinir import build_sr_model
+        model = build_sr_model(args.arch, scale_int).to(device)
     else:
         model = MS_ResUNet().to(device)
     ckpt = None
