@@ -139,10 +139,11 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   kernel adds their sum to dW in a fixed order, or every split adds into dW with fp32 atomics (order-dependent
  *   rounding, ~20 us slower per launch; also what happens when no workspace is registered).
  * Unknown names return SRK_E_UNSUPPORTED.
- * Scope: the values are per THREAD (thread_local inside the library): srk_set_option / srk_get_option act on the calling thread's
- * defaults only.  A plan carries its own values -- srk_swinir_plan_set_option -- which replace the thread's for the duration of each
- * call on that plan, so two plans with different options can live in one process.  The cached device properties and the
- * "LDS limit raised" flags of the kernels are keyed by device id. */
+ * Scope: srk_set_option / srk_get_option act on ONE process-wide value per option (every thread reads it, including the autograd
+ * engine's backward thread).  A plan carries its own values -- srk_swinir_plan_set_option -- which hold, in a thread-private copy of
+ * the option set, for the duration of each call on that plan: two plans with different options can live in one process and run on
+ * two threads.  "probe_stride" belongs to the one-per-process timing probe.  The cached device properties and the "LDS limit raised"
+ * flags of the kernels are keyed by device id. */
 int srk_set_option(const char* name, int value);
 int srk_get_option(const char* name, int* value);
 
@@ -471,7 +472,7 @@ int srk_swinir_plan_create(const srk_swinir_config* cfg, srk_swinir_plan** plan)
 void srk_swinir_plan_destroy(srk_swinir_plan* plan);
 /* Per-plan option values (names and values as srk_set_option): they apply to every later call on this plan (pack, workspace_bytes,
  * forward, forward_features, backward) and to nothing else.  Set them before the first srk_swinir_workspace_bytes query: some options
- * change the workspace layout.  get: *is_set = 1 when the plan carries the value, 0 when the calling thread's default applies. */
+ * change the workspace layout.  get: *is_set = 1 when the plan carries the value, 0 when the process-wide value applies. */
 int srk_swinir_plan_set_option(srk_swinir_plan* plan, const char* name, int value);
 int srk_swinir_plan_get_option(const srk_swinir_plan* plan, const char* name, int* value, int* is_set);
 

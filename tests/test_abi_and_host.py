@@ -94,9 +94,10 @@ def test_index_entry_points_validate_arguments_without_a_gpu(lib):
     assert h.srk_window_partition(C.c_void_p(16), C.c_void_p(16), 1, 13, 8, 3, 8, 4, None) == -1
 
 
-def test_options_are_per_thread_and_per_plan():
-    """SURVEY 8b 'stateless, re-entrant': srk_set_option acts on the calling thread's defaults; a plan carries its own values
-    (srk_swinir_plan_set_option) and its calls leave the thread's defaults as they were.  Host-only: no kernel runs."""
+def test_options_are_process_wide_with_per_plan_values():
+    """SURVEY 8b 're-entrant': srk_set_option writes ONE process-wide value per option (every thread sees it -- the autograd engine runs
+    the backward on its own thread); a plan carries its own values (srk_swinir_plan_set_option), applied in a thread-private copy of the
+    option set around each of its calls, which leaves the process-wide values as they were.  Host-only: no kernel runs."""
     import ctypes as C
     import threading
     from tpu_superresolution_amd import _lib
@@ -114,17 +115,20 @@ def test_options_are_per_thread_and_per_plan():
     seen = {}
 
     def other():
+        seen["before"] = get("attn_fused")
         check(L.srk_set_option(b"attn_fused", 0))
         seen["other"] = get("attn_fused")
+    check(L.srk_set_option(b"attn_fused", 1))
     t = threading.Thread(target=other)
     t.start()
     t.join()
-    assert seen["other"] == 0 and get("attn_fused") == base          # another thread's setting is its own
+    assert seen["before"] == 1 and seen["other"] == 0 and get("attn_fused") == 0      # one value, whichever thread wrote it
+    check(L.srk_set_option(b"attn_fused", base))
     plan = SwinIRPlan(img_size=16, in_chans=3, embed_dim=24, depths=(2,), num_heads=(2,), window_size=8, mlp_ratio=2, upscale=2, img_range=1.0,
                       upsampler="pixelshuffle", options={"attn_fused": 1, "gemm_stream_bm": 32})
     assert plan.get_option("attn_fused") == (1, True) and plan.get_option("gemm_stream_bm") == (32, True)
     assert plan.get_option("mlp_fused") == (1, False)
-    assert get("attn_fused") == base and get("gemm_stream_bm") == 0        # setting a plan's option does not touch the thread's default
+    assert get("attn_fused") == base and get("gemm_stream_bm") == 0        # setting a plan's option does not touch the process-wide value
     n0 = L.srk_swinir_workspace_bytes(plan.handle, 2, 16, 16, 1)            # a plan call applies and restores
     assert n0 > 0 and get("attn_fused") == base and get("gemm_stream_bm") == 0
     with pytest.raises(Exception, match="gemm_stream_bm"):

@@ -327,5 +327,7 @@ def test_hat_width_180_backward_fused_mlp_kernel_vs_separate_kernels():
     for n in res[0][1]:
         rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
         worst = max(worst, rel)
-        assert rel <= 2e-3, (n, rel)         # d u leaves the fused kernel's LDS in bf16 exactly as the separate path stores it; fp32 atomics differ in order
+        # the fused kernel keeps d xn2 in fp32 between the fc1 dgrad and the LayerNorm backward and rounds the DropPath-scaled copy once
+        # (the separate path rounds d xn2 to bf16 and scales a bf16 copy): bf16-level differences, largest on the bias-table gradients
+        assert rel <= 1e-2, (n, rel)
     print("worst relative gradient difference", worst)

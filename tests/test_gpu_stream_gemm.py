@@ -360,3 +360,33 @@ def test_two_plans_with_different_options_share_a_process():
     v = C.c_int()
     check(lib().srk_get_option(b"attn_fused", C.byref(v)))
     assert v.value == 2
+
+
+def test_options_reach_the_autograd_backward_thread():
+    """The autograd engine runs CUDA backward nodes on its own thread: an option written with srk_set_option on the main thread must be
+    what a backward node reads there (the A/B tests of the backward kernels rely on it), and a different thread id is really involved."""
+    import ctypes as C
+    import threading
+    from tpu_superresolution_amd._lib import check, lib
+    seen = {}
+
+    class Spy(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            v = C.c_int()
+            check(lib().srk_get_option(b"mlp_bwd_fused", C.byref(v)))
+            seen["value"], seen["thread"] = v.value, threading.get_ident()
+            return g
+
+    x = torch.ones(4, device="cuda", requires_grad=True)
+    try:
+        check(lib().srk_set_option(b"mlp_bwd_fused", 0))
+        Spy.apply(x).sum().backward()
+    finally:
+        check(lib().srk_set_option(b"mlp_bwd_fused", 1))
+    assert seen["value"] == 0
+    assert seen["thread"] != threading.get_ident()

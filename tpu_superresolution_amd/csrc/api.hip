@@ -9,6 +9,30 @@
 
 static thread_local char g_err[512] = "";
 
+SrkOptTls& srk_opt_tls() {
+  static thread_local SrkOptTls t = {};
+  return t;
+}
+
+static SrkOpt** opt_table() {
+  static SrkOpt* table[SRK_NUM_OPTS] = {};
+  return table;
+}
+
+void srk_opt_register(SrkOpt* o) {
+  if (o->id >= 0 && o->id < SRK_NUM_OPTS) opt_table()[o->id] = o;
+}
+
+void srk_opt_scope_begin(SrkOptTls* saved) {
+  SrkOptTls& t = srk_opt_tls();
+  *saved = t;
+  for (int i = 0; i < SRK_NUM_OPTS; ++i)
+    if (!((t.on >> i) & 1u) && opt_table()[i]) t.v[i] = opt_table()[i]->value;
+  t.on = (1u << SRK_NUM_OPTS) - 1u;
+}
+
+void srk_opt_scope_end(const SrkOptTls& saved) { srk_opt_tls() = saved; }
+
 int srk_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SRK_MAX_DEVICES) return 0;
@@ -286,8 +310,9 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
 }
 
 // ---- options ---------------------------------------------------------------------------------------------------------------------------
-// Every option is a per-THREAD default (thread_local in the kernel sources): srk_set_option changes the calling thread's values and
-// nothing else, a plan carries its own values (srk_swinir_plan_set_option) and applies them around each of its calls.
+// Every option has ONE process-wide value (srk_set_option: seen by every thread, including the autograd engine's backward thread); a
+// plan carries its own values (srk_swinir_plan_set_option), which live in a thread-private copy of the option set for the duration of
+// each call on that plan (common.h: SrkOpt) -- two plans with different options can run in one process, also on two threads.
 namespace {
 
 int tune_get(int which) {

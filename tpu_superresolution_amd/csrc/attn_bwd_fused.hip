@@ -376,7 +376,7 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     *reinterpret_cast<float4*>(slab + 16 * jt) = make_float4(dbias[jt][0], dbias[jt][1], dbias[jt][2], dbias[jt][3]);
 }
 
-thread_local int g_attn_bwd_fused = 1;
+SrkOpt g_attn_bwd_fused{OPT_ATTN_BWD_FUSED, 1};
 
 }  // namespace
 

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 3) void qkv_attn_fwd3_kernel(const FusedParams
 #ifndef SRK_ATTN_FUSED_DEFAULT
 #define SRK_ATTN_FUSED_DEFAULT 2
 #endif
-thread_local int g_attn_fused = SRK_ATTN_FUSED_DEFAULT;            // 0 separate kernels, 1 one 8-wave workgroup per CU, 2 three 4-wave workgroups per CU
+SrkOpt g_attn_fused{OPT_ATTN_FUSED, SRK_ATTN_FUSED_DEFAULT};            // 0 separate kernels, 1 one 8-wave workgroup per CU, 2 three 4-wave workgroups per CU
 
 }  // namespace
 

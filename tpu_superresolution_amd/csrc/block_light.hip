@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void swin_block_light_kernel(const LightPar
   LIGHT_MARK(14);
 }
 
-thread_local int g_block_light = 1;
+SrkOpt g_block_light{OPT_BLOCK_LIGHT, 1};
 
 }  // namespace
 

@@ -24,6 +24,41 @@ int srk_check_launch(const char* what);
 constexpr int SRK_MAX_DEVICES = 64;
 int srk_current_device();     // hipGetDevice, clamped to [0, SRK_MAX_DEVICES)
 int srk_device_cus();         // multiProcessorCount of the current device (cached), -1 when it cannot be read
+// Kernel-variant options (srk_set_option).  Each has a process-wide value -- what srk_set_option writes and what every thread reads,
+// including the autograd engine's backward thread -- and, while a plan call is running on a thread, a thread-private copy that
+// carries the plan's own values (srk_swinir_plan_set_option): reads and writes go to the private copy while its bit is set.
+enum SrkOptId {
+  OPT_MLP_FUSED, OPT_MLP_BWD_FUSED, OPT_GEMM_STREAM, OPT_TUNE_BM, OPT_TUNE_KS2, OPT_TUNE_SPLIT, OPT_TUNE_NB, OPT_ATTN_BWD_FUSED,
+  OPT_ATTN_FUSED, OPT_BLOCK_LIGHT, OPT_TAPS_ENABLED, OPT_TAPS_DMA, OPT_WGRAD_STREAM, OPT_WGRAD_ROWS, OPT_WGRAD_NT, OPT_WGRAD_W8,
+  OPT_WGRAD_PARTIALS, SRK_NUM_OPTS
+};
+struct SrkOptTls {
+  int v[SRK_NUM_OPTS];
+  unsigned on;
+};
+SrkOptTls& srk_opt_tls();                 // this thread's private copies (api.hip)
+struct SrkOpt;
+void srk_opt_register(SrkOpt* o);
+void srk_opt_scope_begin(SrkOptTls* saved);   // private copies of ALL options for this thread (snapshot of the effective values)
+void srk_opt_scope_end(const SrkOptTls& saved);
+struct SrkOpt {
+  int id;
+  int value;                              // process-wide
+  SrkOpt(int id_, int v) : id(id_), value(v) { srk_opt_register(this); }
+  operator int() const {
+    const SrkOptTls& t = srk_opt_tls();
+    return ((t.on >> id) & 1u) ? t.v[id] : value;
+  }
+  SrkOpt& operator=(int v) {
+    SrkOptTls& t = srk_opt_tls();
+    if ((t.on >> id) & 1u) t.v[id] = v;
+    else value = v;
+    return *this;
+  }
+  SrkOpt(const SrkOpt&) = delete;
+  SrkOpt& operator=(const SrkOpt&) = delete;
+};
+
 template <class T>
 struct SrkPerDevice {
   T v[SRK_MAX_DEVICES] = {};

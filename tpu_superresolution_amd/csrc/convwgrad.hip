@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(const WgradParams 
   }
 }
 
-thread_local int g_taps_enabled = 1;
+SrkOpt g_taps_enabled{OPT_TAPS_ENABLED, 1};
 
 template <bool SHUF>
 int launch_taps(const WgradParams& p, hipStream_t stream) {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_reduce_kernel(const Wgrad
   for (int e = 0; e < 4; ++e) atomicAdd(p.dW + (long long)(n + e) * p.ldw + col, sum[e]);
 }
 
-thread_local int g_taps_dma = 1;
+SrkOpt g_taps_dma{OPT_TAPS_DMA, 1};
 
 template <bool SHUF>
 int launch_taps_dma(const WgradParams& p, hipStream_t stream) {

@@ -1208,15 +1208,15 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(const GemmParams p, 
   }
 }
 
-thread_local int g_mlp_fused_enabled = 1;
-thread_local int g_mlp_bwd_fused_enabled = 1;
+SrkOpt g_mlp_fused_enabled{OPT_MLP_FUSED, 1};
+SrkOpt g_mlp_bwd_fused_enabled{OPT_MLP_BWD_FUSED, 1};
 
-thread_local int g_stream_enabled = -1;     // -1: read SRK_GEMM_STREAM once
+SrkOpt g_stream_enabled{OPT_GEMM_STREAM, -1};     // -1: read SRK_GEMM_STREAM once
 thread_local int g_num_cus = 0;      // CU count of the device the current launch goes to (refreshed by every launcher)
-thread_local int g_tune_bm = 0;             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
-thread_local int g_tune_ks2 = -1;           // split K over the two wave groups: 0/1, -1 = default
-thread_local int g_tune_split = -1;         // role-split kernel (MFMA on the loader waves): 0/1, -1 = default
-thread_local int g_tune_nb = 0;             // role-split kernel: epilogue waves 4/8, 0 = default
+SrkOpt g_tune_bm{OPT_TUNE_BM, 0};             // tuning overrides (srk_set_option): rows per tile 16/32/64, 0 = per-epilogue default
+SrkOpt g_tune_ks2{OPT_TUNE_KS2, -1};           // split K over the two wave groups: 0/1, -1 = default
+SrkOpt g_tune_split{OPT_TUNE_SPLIT, -1};         // role-split kernel (MFMA on the loader waves): 0/1, -1 = default
+SrkOpt g_tune_nb{OPT_TUNE_NB, 0};             // role-split kernel: epilogue waves 4/8, 0 = default
 
 template <typename KernelT>
 int stream_configure(KernelT kernel, int lds, int* state) {

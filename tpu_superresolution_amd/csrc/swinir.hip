@@ -233,21 +233,19 @@ struct Arena {
   }
 };
 
-// The plan's option values replace the calling thread's for the duration of one plan call (the kernel launchers read thread-local
-// values: two plans with different options can share a process, and a thread's defaults are back when the call returns).
+// The plan's option values hold for the duration of one plan call on the calling thread: the thread gets a private copy of the option
+// set (common.h: SrkOpt) into which the plan's values are written; the process-wide values are untouched.
 struct PlanOptionScope {
-  std::vector<std::pair<const char*, int>> saved;
+  SrkOptTls saved;
+  bool active = false;
   explicit PlanOptionScope(const srk_swinir_plan* p) {
-    if (!p) return;
-    for (const auto& o : p->options) {
-      int old = 0;
-      if (srk_get_option(o.first.c_str(), &old) != SRK_OK) continue;
-      saved.emplace_back(o.first.c_str(), old);
-      srk_set_option(o.first.c_str(), o.second);
-    }
+    if (!p || p->options.empty()) return;
+    srk_opt_scope_begin(&saved);
+    active = true;
+    for (const auto& o : p->options) srk_set_option(o.first.c_str(), o.second);
   }
   ~PlanOptionScope() {
-    for (auto it = saved.rbegin(); it != saved.rend(); ++it) srk_set_option(it->first, it->second);
+    if (active) srk_opt_scope_end(saved);
   }
   PlanOptionScope(const PlanOptionScope&) = delete;
   PlanOptionScope& operator=(const PlanOptionScope&) = delete;
@@ -654,10 +652,12 @@ int srk_swinir_plan_set_option(srk_swinir_plan* plan, const char* name, int valu
   SRK_REQUIRE(plan && name, SRK_E_NULL, "plan_set_option: null argument");
   int old = 0;
   RUN(srk_get_option(name, &old));              // unknown names fail here
-  const int rc = srk_set_option(name, value);   // validates the value ...
+  SrkOptTls saved;
+  srk_opt_scope_begin(&saved);                  // validate (and normalise) the value on a private copy of the option set
+  const int rc = srk_set_option(name, value);
   int stored = value;
   if (rc == SRK_OK) srk_get_option(name, &stored);
-  srk_set_option(name, old);                    // ... and leaves the thread's default as it was
+  srk_opt_scope_end(saved);
   if (rc != SRK_OK) return rc;
   for (auto& o : plan->options)
     if (o.first == name) {

@@ -380,14 +380,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradMulti mp) 
 thread_local const RpbJob* t_rpb = nullptr;     // job offered by srk_launch_wgrad_multi_rpb to the next reduce launch of this thread
 thread_local bool t_rpb_done = false;
 
-thread_local int g_wgrad_stream = 1;
-thread_local int g_wgrad_rows = 32;      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
-thread_local int g_wgrad_nt = 1;         // nt (streaming) cache policy on its operand DMAs
+SrkOpt g_wgrad_stream{OPT_WGRAD_STREAM, 1};
+SrkOpt g_wgrad_rows{OPT_WGRAD_ROWS, 32};      // rows per ring stage of the streaming kernel: 32 (6 stages) or 64 (3 stages)
+SrkOpt g_wgrad_nt{OPT_WGRAD_NT, 1};         // nt (streaming) cache policy on its operand DMAs
 #ifndef SRK_WGRAD_W8_DEFAULT
 #define SRK_WGRAD_W8_DEFAULT 1
 #endif
-thread_local int g_wgrad_w8 = SRK_WGRAD_W8_DEFAULT;   // eight waves per workgroup (two per SIMD) in the streaming kernel
-thread_local int g_wgrad_partials = 1;   // split partials to scratch slabs + reduce kernel (1) or fp32 atomics straight into dW (0)
+SrkOpt g_wgrad_w8{OPT_WGRAD_W8, SRK_WGRAD_W8_DEFAULT};   // eight waves per workgroup (two per SIMD) in the streaming kernel
+SrkOpt g_wgrad_partials{OPT_WGRAD_PARTIALS, 1};   // split partials to scratch slabs + reduce kernel (1) or fp32 atomics straight into dW (0)
 
 template <int TA, int TB, bool CONV>
 int launch(const WgradParams* ps, int nprob, hipStream_t stream) {
