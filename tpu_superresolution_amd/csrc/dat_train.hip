@@ -311,117 +311,170 @@ __global__ __launch_bounds__(256) void dual_gate_bwd_kernel(const bf16_t* __rest
 }
 
 // ---- spatial interaction: y1 = W0 x + b0 (S <= 16 outputs), z = y1 * s + t (BatchNorm), a = gelu(z), smap = w3 . a + b3 ---------------
-// One thread per token (the S x C weights staged in LDS); reductions over the workgroup's tokens by warp shuffles + LDS.
-template <int WHAT>      // 0: stats of y1 (sum, sum sq)   1: backward stats (sum dz, sum dz y1, sum dsmap a, sum dsmap)
-                         // 2: backward apply: dy1 = A dz + B y1 + C -> dx[t][c] (+)= sum_s W0[s][c] dy1[s]; dW0 / db0 partials
+// 16 lanes per token (lane j holds channels 64 i + 4 j .. + 3, the LayerNorm layout: a token row is read as contiguous 128-byte runs),
+// 16 tokens per workgroup step, 16 steps per workgroup (256 tokens).  y1[s] by a 16-lane all-reduce per s; W0 and the per-s vectors in
+// LDS.  WHAT 0: statistics of y1 (sum, sum sq).  WHAT 1: backward statistics (sum dz, sum dz y1, sum dsmap a, sum dsmap) with
+// dz = dsmap * w3 * gelu'(z).  WHAT 2: dy1 = A dz + B y1 + C; dx (+)= W0^T dy1 per lane (coalesced stores); d W0 [s][c] += dy1[s] x[c]
+// through LDS (thread c owns column c and keeps its 16 sums in registers across the steps); d b0 = sum dy1.
+template <int WHAT, int NV>
 __global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ W0,
                                                                  const float* __restrict__ b0, const float* __restrict__ sc,
                                                                  const float* __restrict__ sh, const float* __restrict__ w3,
                                                                  const float* __restrict__ dsmap, const float* __restrict__ cA,
                                                                  const float* __restrict__ cB, const float* __restrict__ cC,
                                                                  bf16_t* __restrict__ dx, int lddx, int accumulate,
-                                                                 float* __restrict__ partial, long long rows, int C, int S) {
+                                                                 float* __restrict__ partial, long long rows, int S) {
+  constexpr int C = NV * 64;
+  constexpr int NVAL = WHAT == 0 ? 2 : 4;
   extern __shared__ float sm[];
-  float* Wl = sm;                        // [S][C]
-  float* red = sm + S * C;               // [256][4 * 16] max
-  const int tid = threadIdx.x;
-  for (int i = tid; i < S * C; i += 256) Wl[i] = W0[i];
-  __syncthreads();
-  const long long t = (long long)blockIdx.x * 256 + tid;
-  const bool ok = t < rows;
-  float y1[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) y1[s] = s < S ? b0[s] : 0.f;
-  if (ok) {
-    for (int c = 0; c < C; c += 8) {
-      const uint4 xv = *reinterpret_cast<const uint4*>(x + t * ldx + c);
-      float v[8];
-      unpack_bf2(xv.x, v[0], v[1]); unpack_bf2(xv.y, v[2], v[3]); unpack_bf2(xv.z, v[4], v[5]); unpack_bf2(xv.w, v[6], v[7]);
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        if (s < S) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y1[s] = fmaf(Wl[s * C + c + e], v[e], y1[s]);
-        }
-    }
+  float* Wl = sm;                        // [16][C], rows >= S zero
+  float* vec = Wl + 16 * C;              // [7][16]: b0, sc, sh, w3, cA, cB, cC (zero beyond S)
+  float* red = vec + 7 * 16;             // WHAT 0 / 1: [16 groups][NVAL * 16]; WHAT 2: dyl [16][16] + xs [16][C]
+  const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
+  for (int i = tid; i < 16 * C; i += 256) Wl[i] = i < S * C ? W0[i] : 0.f;
+  if (tid < 7 * 16) {
+    const int which = tid >> 4, s = tid & 15;
+    const float* src = which == 0 ? b0 : which == 1 ? sc : which == 2 ? sh : which == 3 ? w3 : which == 4 ? cA : which == 5 ? cB : cC;
+    vec[tid] = (src != nullptr && s < S) ? src[s] : 0.f;
   }
-  constexpr int NV = WHAT == 0 ? 2 : (WHAT == 1 ? 4 : 1);
-  float vals[NV][16];
-  float dy1[16];
-  if constexpr (WHAT == 0) {
+  __syncthreads();
+  float acc[NVAL][16];                   // WHAT 0 / 1: per-token sums (identical in the 16 lanes of a token)
+  float dwa[16];                         // WHAT 2: d W0[s][tid]
+  float dba[16];                         // WHAT 2: d b0 (per group)
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) acc[k][s] = 0.f;
+    dwa[s] = dba[s] = 0.f;
+  }
+  float* dyl = red;                      // [16 tokens][16]
+  float* xs = red + 256;                 // [16 tokens][C]
+#pragma unroll 1
+  for (int it = 0; it < 16; ++it) {
+    const long long t = (long long)blockIdx.x * 256 + it * 16 + grp;
+    const bool ok = t < rows;
+    float xv[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      uint2 u = make_uint2(0, 0);
+      if (ok) u = *reinterpret_cast<const uint2*>(x + t * ldx + 64 * i + 4 * j);
+      unpack_bf2(u.x, xv[i][0], xv[i][1]);
+      unpack_bf2(u.y, xv[i][2], xv[i][3]);
+    }
+    float y1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      vals[0][s] = ok ? y1[s] : 0.f;
-      vals[1][s] = ok ? y1[s] * y1[s] : 0.f;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 wv = *reinterpret_cast<const float4*>(Wl + s * C + 64 * i + 4 * j);
+        d += xv[i][0] * wv.x + xv[i][1] * wv.y + xv[i][2] * wv.z + xv[i][3] * wv.w;
+      }
+      y1[s] = wave_sum16(d) + vec[s];
+    }
+    if constexpr (WHAT == 0) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc[0][s] += ok ? y1[s] : 0.f;
+        acc[1][s] += ok ? y1[s] * y1[s] : 0.f;
+      }
+    } else {
+      const float ds = ok ? dsmap[t] : 0.f;
+      float dy1[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float z = y1[s] * vec[16 + s] + vec[32 + s];
+        const float dz = ds * vec[48 + s] * dgelu_shared_exp(z);
+        if constexpr (WHAT == 1) {
+          acc[0][s] += dz;
+          acc[1][s] += dz * y1[s];
+          acc[2][s] += s < S ? ds * gelu_f(z) : 0.f;
+          acc[3][s] += s == 0 ? ds : 0.f;
+        } else {
+          dy1[s] = (ok && s < S) ? vec[64 + s] * dz + vec[80 + s] * y1[s] + vec[96 + s] : 0.f;
+          dba[s] += dy1[s];
+        }
+      }
+      if constexpr (WHAT == 2) {
+        if (ok) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            if (accumulate) {
+              const uint2 u = *reinterpret_cast<const uint2*>(dx + t * lddx + 64 * i + 4 * j);
+              unpack_bf2(u.x, o[0], o[1]);
+              unpack_bf2(u.y, o[2], o[3]);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+              const float4 wv = *reinterpret_cast<const float4*>(Wl + s * C + 64 * i + 4 * j);
+              o[0] = fmaf(wv.x, dy1[s], o[0]);
+              o[1] = fmaf(wv.y, dy1[s], o[1]);
+              o[2] = fmaf(wv.z, dy1[s], o[2]);
+              o[3] = fmaf(wv.w, dy1[s], o[3]);
+            }
+            *reinterpret_cast<uint2*>(dx + t * lddx + 64 * i + 4 * j) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+          }
+        }
+        // d W0: the 16 tokens' dy1 and x rows through LDS, thread c accumulates column c
+        __syncthreads();                 // the previous step's readers are done
+        if (j == 0) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            *reinterpret_cast<float4*>(dyl + grp * 16 + 4 * s4) = make_float4(dy1[4 * s4], dy1[4 * s4 + 1], dy1[4 * s4 + 2], dy1[4 * s4 + 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          *reinterpret_cast<float4*>(xs + grp * C + 64 * i + 4 * j) = make_float4(xv[i][0], xv[i][1], xv[i][2], xv[i][3]);
+        __syncthreads();
+        if (tid < C) {
+#pragma unroll 4
+          for (int k = 0; k < 16; ++k) {
+            const float xk = xs[k * C + tid];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const float4 d = *reinterpret_cast<const float4*>(dyl + k * 16 + 4 * s4);
+              dwa[4 * s4] = fmaf(d.x, xk, dwa[4 * s4]);
+              dwa[4 * s4 + 1] = fmaf(d.y, xk, dwa[4 * s4 + 1]);
+              dwa[4 * s4 + 2] = fmaf(d.z, xk, dwa[4 * s4 + 2]);
+              dwa[4 * s4 + 3] = fmaf(d.w, xk, dwa[4 * s4 + 3]);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if constexpr (WHAT != 2) {
+    if (j == 0) {
+#pragma unroll
+      for (int k = 0; k < NVAL; ++k)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) red[grp * (NVAL * 16) + k * 16 + s] = acc[k][s];
+    }
+    __syncthreads();
+    if (tid < NVAL * 16) {
+      float t = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 16; ++gq) t += red[gq * (NVAL * 16) + tid];
+      partial[(long long)blockIdx.x * (NVAL * 16) + tid] = t;
     }
   } else {
-    const float ds = ok ? dsmap[t] : 0.f;
+    float* dst = partial + (long long)blockIdx.x * 16 * (C + 1);
+    if (tid < C) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float z = y1[s] * (s < S ? sc[s] : 0.f) + (s < S ? sh[s] : 0.f);
-      const float a = gelu_f(z);
-      const float dz = s < S ? ds * w3[s] * dgelu_shared_exp(z) : 0.f;       // d a = dsmap * w3, through GELU
-      if constexpr (WHAT == 1) {
-        vals[0][s] = dz;
-        vals[1][s] = dz * y1[s];
-        vals[2][s] = s < S ? ds * a : 0.f;
-        vals[3][s] = s == 0 ? ds : 0.f;
-      } else {
-        dy1[s] = (ok && s < S) ? cA[s] * dz + cB[s] * y1[s] + cC[s] : 0.f;
-        vals[0][s] = dy1[s];
-      }
+      for (int s = 0; s < 16; ++s) dst[s * C + tid] = dwa[s];
     }
-  }
-  // workgroup sums of vals -> partial[block][NV][16]
-  float* mine = red + tid * (NV * 16);
+    if (j == 0) {
 #pragma unroll
-  for (int k = 0; k < NV; ++k)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) mine[k * 16 + s] = vals[k][s];
-  __syncthreads();
-  if (tid < NV * 16) {
-    float s = 0.f;
-    for (int k = 0; k < 256; ++k) s += red[k * (NV * 16) + tid];
-    const int base = WHAT == 2 ? 16 * (C + 1) : NV * 16;
-    partial[(long long)blockIdx.x * base + (WHAT == 2 ? 16 * C : 0) + tid] = s;       // WHAT 2: db0 partial behind the dW0 partial
-  }
-  if constexpr (WHAT == 2) {
-    // d x = W0^T dy1 (per token); dW0[s][c] partial = sum over the workgroup's tokens of dy1[s] x[c]
-    if (ok) {
-      for (int c = 0; c < C; c += 8) {
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (accumulate) {
-          const uint4 ov = *reinterpret_cast<const uint4*>(dx + t * lddx + c);
-          unpack_bf2(ov.x, o[0], o[1]); unpack_bf2(ov.y, o[2], o[3]); unpack_bf2(ov.z, o[4], o[5]); unpack_bf2(ov.w, o[6], o[7]);
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-          if (s < S) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(Wl[s * C + c + e], dy1[s], o[e]);
-          }
-        *reinterpret_cast<uint4*>(dx + t * lddx + c) =
-            make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
-      }
+      for (int s = 0; s < 16; ++s) red[grp * 16 + s] = dba[s];
     }
-    // dW0 partial: stage dy1 of the 256 tokens in LDS, then thread = channel pair walks the tokens
     __syncthreads();
-    float* dyl = red;                     // [256][16]
+    if (tid < 16) {
+      float t = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) dyl[tid * 16 + s] = dy1[s];
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-      float acc[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc[s] = 0.f;
-      const long long t0 = (long long)blockIdx.x * 256;
-      for (int k = 0; k < 256 && t0 + k < rows; ++k) {
-        const float xv = bf2f(x[(t0 + k) * ldx + c]);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc[s] = fmaf(dyl[k * 16 + s], xv, acc[s]);
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) partial[(long long)blockIdx.x * 16 * (C + 1) + s * C + c] = acc[s];
+      for (int gq = 0; gq < 16; ++gq) t += red[gq * 16 + tid];
+      dst[16 * C + tid] = t;
     }
   }
 }
@@ -688,31 +741,35 @@ int srk_spatial_gate_train(int what, const uint16_t* x, int ldx, const float* W0
   REQP(rows > 0 && C > 0 && C % 8 == 0 && C <= 256 && S > 0 && S <= 16 && ldx % 8 == 0 && what >= 0 && what <= 2, "spatial_gate_train: bad shape");
   SRK_REQUIRE(what == 0 || (bn_scale && bn_shift && w3 && dsmap), SRK_E_NULL, "spatial_gate_train: backward operands missing");
   SRK_REQUIRE(what != 2 || (cA && cB && cC && dx && lddx % 8 == 0), SRK_E_NULL, "spatial_gate_train: apply operands missing");
+  REQP(C % 64 == 0, "spatial_gate_train: C must be a multiple of 64 (the head-padded width)");
   const unsigned grid = (unsigned)((rows + 255) / 256);
-  const size_t lds = (size_t)(S * C + 256 * 64) * sizeof(float);
-  static SrkPerDevice<bool> configured_pd; bool& configured = configured_pd.here();
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess) {
-      srk_set_error("spatial_gate_train: cannot reserve LDS");
-      return SRK_E_LAUNCH;
-    }
-    configured = true;
-  }
   hipStream_t st = (hipStream_t)stream;
-  if (what == 0)
-    hipLaunchKernelGGL(spatial_gate_train_kernel<0>, dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3, dsmap, cA, cB, cC, dx,
-                       lddx, accumulate, partial, (long long)rows, C, S);
-  else if (what == 1)
-    hipLaunchKernelGGL(spatial_gate_train_kernel<1>, dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3, dsmap, cA, cB, cC, dx,
-                       lddx, accumulate, partial, (long long)rows, C, S);
-  else
-    hipLaunchKernelGGL(spatial_gate_train_kernel<2>, dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3, dsmap, cA, cB, cC, dx,
-                       lddx, accumulate, partial, (long long)rows, C, S);
+#define SGT_LAUNCH(WHAT_, NV_)                                                                                                              \
+  {                                                                                                                                         \
+    constexpr size_t lds = (size_t)(16 * NV_ * 64 + 7 * 16 + (WHAT_ == 2 ? 256 + 16 * NV_ * 64 : 16 * 64)) * sizeof(float);                 \
+    static SrkPerDevice<bool> configured_pd;                                                                                                \
+    bool& configured = configured_pd.here();                                                                                                \
+    if (!configured) {                                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_gate_train_kernel<WHAT_, NV_>),                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                                        \
+        srk_set_error("spatial_gate_train: cannot reserve LDS");                                                                            \
+        return SRK_E_LAUNCH;                                                                                                                \
+      }                                                                                                                                     \
+      configured = true;                                                                                                                    \
+    }                                                                                                                                       \
+    hipLaunchKernelGGL((spatial_gate_train_kernel<WHAT_, NV_>), dim3(grid), dim3(256), lds, st, x, ldx, W0, b0, bn_scale, bn_shift, w3,     \
+                       dsmap, cA, cB, cC, dx, lddx, accumulate, partial, (long long)rows, S);                                               \
+  }
+#define SGT_NV(WHAT_)                                  \
+  switch (C / 64) {                                    \
+    case 1: SGT_LAUNCH(WHAT_, 1) break;                \
+    case 2: SGT_LAUNCH(WHAT_, 2) break;                \
+    case 3: SGT_LAUNCH(WHAT_, 3) break;                \
+    default: SGT_LAUNCH(WHAT_, 4) break;               \
+  }
+  if (what == 0) SGT_NV(0) else if (what == 1) SGT_NV(1) else SGT_NV(2)
+#undef SGT_NV
+#undef SGT_LAUNCH
   return srk_check_launch("spatial_gate_train");
 }
 
