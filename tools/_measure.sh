@@ -26,4 +26,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/m_prof_cfg2 -- python3 /root/repo/bench.py --config cfg2 --no-cpu-baseline --no-roofline --no-graph --steps 50 --warmup 2 > /dev/null 2>/root/repo/gpurun_out/m_prof_cfg2.err
 cd /root/repo
 python tools/sq_summary.py gpurun_out s_ > gpurun_out/m_sq.txt
+timeout -k 10 120 python __graft_entry__.py --smoke > gpurun_out/m_smoke.log 2>&1
+tail -2 gpurun_out/m_smoke.log
 cut -c1-500 gpurun_out/m_bench.json
