@@ -553,3 +553,24 @@ def test_graphed_train_step_matches_eager_steps():
     for (n, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
         if n.endswith("num_batches_tracked"):
             assert int(ba) == int(bb) == 5
+
+
+def test_dat_width_180_train_step_vs_oracle():
+    """The official DAT width (embed 180, 6 heads, split 8x32, expansion 4; two blocks: one spatial, one channel) with 16 384 tokens: here the
+    persistent streaming GEMMs run -- incl. the qkv dgrad with the norm1 backward in its epilogue (SRK_EP_LNBWD in token order) -- where
+    the tiny-model tests take the tile kernels.  Loss, output and every gradient against the training oracle."""
+    cfg = DO.DATConfig(**{**DO.DATConfig.sr_x4().__dict__, "depth": (2,), "num_heads": (6,), "upscale": 2})
+    sd = DO.random_state_dict(cfg, seed=41, scale=1.0)
+    m = _train_model(cfg, sd)
+    gen = torch.Generator().manual_seed(12)
+    x, t = torch.rand(4, 3, 64, 64, generator=gen), torch.rand(4, 3, 128, 128, generator=gen)
+    y = m(x.cuda())
+    loss = F.l1_loss(y, t.cuda())
+    loss.backward()
+    lo, yo, grads, rec = DO.loss_and_grads(sd, cfg, x, t)
+    assert float((y.detach().cpu() - yo).abs().max()) <= 2e-2 * float(yo.abs().max())
+    assert abs(float(loss.detach()) - lo) <= 5e-3 * lo
+    _check_grads(m, grads)
+    for n, b in m.named_buffers():
+        if n.endswith("running_var"):
+            assert float((b.cpu() - rec[n]).abs().max()) <= 2e-2 * max(float(rec[n].abs().max()), 1e-2), n
