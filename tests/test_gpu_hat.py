@@ -331,3 +331,36 @@ def test_hat_width_180_backward_fused_mlp_kernel_vs_separate_kernels():
         # (the separate path rounds d xn2 to bf16 and scales a bf16 copy): bf16-level differences, largest on the bias-table gradients
         assert rel <= 1e-2, (n, rel)
     print("worst relative gradient difference", worst)
+
+
+def test_hat_width_180_train_step_vs_oracle_autograd():
+    """HAT-SRx4 width (embed 180, 6 heads, window 16, CAB, OCAB; one group of two HABs) with 16 384 tokens -- where the persistent
+    streaming GEMMs, the fused MLP forward / backward kernels and the OCAB's fused LayerNorm-backward epilogue run -- against autograd
+    over the CPU oracle (drop_path 0): loss, output and every parameter's gradient."""
+    import tpu_superresolution_amd as T
+    cfg = HO.HATConfig(**{**HO.HATConfig.sr_x4().__dict__, "depths": (2,), "num_heads": (6,), "upscale": 2})
+    sd = HO.random_state_dict(cfg, seed=8, scale=1.0)
+    m = T.HAT(drop_path_rate=0.0, **cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    gen = torch.Generator().manual_seed(4)
+    x, t = torch.rand(4, 3, 64, 64, generator=gen), torch.rand(4, 3, 128, 128, generator=gen)
+    y = m(x.cuda())
+    loss = torch.nn.functional.l1_loss(y, t.cuda())
+    loss.backward()
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k in dict(m.named_parameters()) else v) for k, v in sd.items()}
+    yo = HO.hat_forward(leaf, cfg, x)
+    lo = (yo - t).abs().mean()
+    names = [n for n, _ in m.named_parameters()]
+    grads = dict(zip(names, torch.autograd.grad(lo, [leaf[n] for n in names], allow_unused=True)))
+    assert float((y.detach().cpu() - yo.detach()).abs().max()) <= 2e-2 * float(yo.abs().max())
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 5e-3 * float(lo.detach())
+    biggest = max(float(g.norm()) for g in grads.values() if g is not None)
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        w = grads[n] if grads[n] is not None else torch.zeros_like(p.detach().cpu())
+        e = float((p.grad.cpu().float() - w).norm()) / max(float(w.norm()), 2e-3 * biggest)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"worst gradient error {worst[1]:.3e} at {worst[0]}")
+    assert worst[1] <= 0.1, worst
