@@ -22,7 +22,7 @@
 // Self-attention windows partition the tokens: dk / dv are stored.  Overlapping key windows share tokens (up to four windows per
 // token): dk / dv are added with fp32 atomics into a zeroed [T][2 CA] buffer that srk_launch_win256_attn_bwd converts afterwards
 // (keys in the zero padding have no token and drop out).  The table gradient leaves as one partial column per workgroup,
-// summed in a fixed order by win256_table_reduce_kernel.
+// summed by win256_table_reduce_kernel (32-window slices, one float atomic per element and slice).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -353,14 +353,26 @@ __global__ __launch_bounds__(256, 1) void win256_attn_bwd_kernel(const Win256Bwd
   for (int i = tid; i < p.table_rows; i += 256) tp[i] = tabg[i];
 }
 
-// d table[i][h] += sum over the (window) workgroups of head h, in workgroup order
+// d table[i][h] += sum over the (window) workgroups of head h: blockIdx.z takes a 32-window slice (eight loads in flight per thread) and adds
+// its sum with one float atomic per element (24 workgroups walking all the windows one dependent load at a time took 65 us)
 __global__ __launch_bounds__(256) void win256_table_reduce_kernel(const float* __restrict__ tpart, float* __restrict__ dtable, int nwin,
                                                                    int nH, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
   if (i >= rows) return;
+  const int w0 = blockIdx.z * 32, w1 = min(nwin, w0 + 32);
+  const float* src = tpart + (long long)h * rows + i;
+  const long long stride = (long long)nH * rows;
   float a = 0.f;
-  for (int wdx = 0; wdx < nwin; ++wdx) a += tpart[((long long)wdx * nH + h) * rows + i];
-  dtable[(long long)i * nH + h] += a;
+  int wdx = w0;
+  for (; wdx + 8 <= w1; wdx += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(wdx + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; wdx < w1; ++wdx) a += src[wdx * stride];
+  atomicAdd(dtable + (long long)i * nH + h, a);
 }
 
 // dqkv[t][CA + c] = bf16(dkv32[t][c]), c < 2 CA
@@ -439,7 +451,7 @@ int srk_launch_win256_attn_bwd(const bf16_t* qkv, int ldq, int CA, const float* 
     rc = launch_bwd<16, false>(p, stream);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(win256_table_reduce_kernel, dim3((table_rows + 255) / 256, nH), dim3(256), 0, stream, p.tpart, dtable, (int)nwin, nH,
+  hipLaunchKernelGGL(win256_table_reduce_kernel, dim3((table_rows + 255) / 256, nH, (unsigned)((nwin + 31) / 32)), dim3(256), 0, stream, p.tpart, dtable, (int)nwin, nH,
                      table_rows);
   return srk_check_launch("win256_table_reduce");
 }
