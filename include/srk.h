@@ -89,6 +89,16 @@ int srk_rel_pos_bias_expand(const float* table, float* bias_dense, int nH, srk_s
 int srk_linear_bf16(const uint16_t* a, const uint16_t* w, const float* bias, uint16_t* y, int M, int N, int K, srk_stream_t stream);
 /* dw[N][K] += y[M][N]^T . x[M][K] ; db[N] += colsum(y)   (bf16 in, fp32 out, accumulating; db may be null) */
 int srk_linear_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, float* db, int M, int N, int K, srk_stream_t stream);
+/* Up to four of these with the same M as ONE launch (the four linear layers of a transformer block: the launch then fills the chip with
+ * few row splits per tile).  Problems whose N and K are all multiples of 192 go out together; any other mix is launched one by one.
+ * ldy / ldx: row strides in elements (0: N / K).  dw [N][K] and db [N] (or null) are ACCUMULATED, as srk_linear_wgrad_bf16. */
+typedef struct {
+  const void* y; int ldy;      /* bf16 [M][ldy]: gradient of the layer output */
+  const void* x; int ldx;      /* bf16 [M][ldx]: layer input */
+  float* dw; float* db;
+  int N, K;
+} srk_wgrad_problem;
+int srk_linear_wgrad_multi_bf16(const srk_wgrad_problem* problems, int count, int M, srk_stream_t stream);
 /* 3x3/s1/p1 conv on NHWC bf16 [B][H][W][CinP] with packed weights [N][9*CinP] (tap-major), + bias -> bf16 NHWC [..][N] */
 int srk_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y, int B, int H, int W, int CinP, int N,
                      srk_stream_t stream);

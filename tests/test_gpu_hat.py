@@ -364,3 +364,47 @@ def test_hat_width_180_train_step_vs_oracle_autograd():
             worst = (n, e)
     print(f"worst gradient error {worst[1]:.3e} at {worst[0]}")
     assert worst[1] <= 0.1, worst
+
+
+def test_hat_graphed_train_step_matches_eager_steps():
+    """training.GraphedTrainStep on HAT (incl. the overlapping cross-attention backward, whose fp32 accumulation image must be re-zeroed by
+    every replay: a hipMemsetAsync node did not do that under capture on this ROCm build, the library now zeroes with its own kernel):
+    losses of four replayed steps on changing batches against the same steps launched eagerly (drop_path 0)."""
+    import tpu_superresolution_amd as T
+    from tpu_superresolution_amd.training import GraphedTrainStep, l1_loss_checked
+    g, cfg, sd = hat_tiny_weights()
+    gen = torch.Generator().manual_seed(9)
+    batches = [(torch.rand(2, 3, 32, 32, generator=gen).cuda(), torch.rand(2, 3, 128, 128, generator=gen).cuda()) for _ in range(4)]
+
+    def model():
+        m = T.HAT(drop_path_rate=0.0, **cfg.kwargs())
+        m.load_state_dict(sd, strict=True)
+        return m.cuda().train()
+    ma, mb = model(), model()
+    oa = torch.optim.AdamW(ma.parameters(), lr=1e-4, weight_decay=0.0)
+    ob = torch.optim.AdamW(mb.parameters(), lr=1e-4, weight_decay=0.0, capturable=True)
+    gs = GraphedTrainStep(mb, ob, max_grad_norm=1.0, warmup=1)
+
+    def eager(x, t):
+        oa.zero_grad(set_to_none=True)
+        loss, _ = l1_loss_checked(ma(x), t)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+        oa.step()
+        return float(loss.detach()), float(gn)
+    eager(*batches[0])                   # the graphed stepper warms up with one eager step on its first batch
+    la, lb = [], []
+    for x, t in batches:
+        la.append(eager(x, t)[0])
+        lg, bad = gs(x, t)
+        lb.append(float(lg))
+        assert int(bad) == 0
+    print("eager", la, "graphed", lb)
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(la, lb))
+    # the gradients the last replay left behind are those of an eager backward at the same weights (not sums over replays)
+    x, t = batches[-1]
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.isfinite(pb.grad).all(), n
+    ga = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in ma.parameters())))
+    gb = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in mb.parameters())))
+    assert abs(ga - gb) <= 0.05 * ga, (ga, gb)          # both were clipped to the same norm from nearly the same raw gradients

@@ -48,6 +48,12 @@ class GemmArgs(C.Structure):
                 ("ln_dbeta", C.c_void_p), ("ln_C", C.c_int)]
 
 
+class WgradProblem(C.Structure):
+    """srk_wgrad_problem (include/srk.h)."""
+    _fields_ = [("y", C.c_void_p), ("ldy", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("N", C.c_int), ("K", C.c_int)]
+
+
 LD_ROWS, LD_CONV3, LD_CONV3_PS = 0, 1, 2
 EP_BF16, EP_GELU, EP_RES, EP_LRELU, EP_PS, EP_IMG, EP_PS_IMG, EP_RES_BF16 = 0, 3, 4, 6, 7, 8, 9, 10
 EP_DGELU, EP_DLRELU, EP_F32_BF16, EP_LNBWD = 5, 11, 12, 13
@@ -132,6 +138,7 @@ _SIGNATURES = {
     "srk_dual_gate_combine": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "srk_channel_attention_workspace": (_sz, [_i, _i, _i]),
     "srk_channel_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srk_linear_wgrad_multi_bf16": (_i, [C.POINTER(WgradProblem), _i, _i, _vp]),
     "srk_mlp_fused_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "srk_win_attention_bwd_padded_scratch": (_sz, [_i, _i, _i, _i, _i, _i]),
     "srk_win_attention_bwd_padded": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),

@@ -246,6 +246,20 @@ int srk_linear_wgrad_bf16(const uint16_t* y, const uint16_t* x, float* dw, float
   return srk_launch_wgrad(p, (hipStream_t)stream);
 }
 
+int srk_linear_wgrad_multi_bf16(const srk_wgrad_problem* problems, int count, int M, srk_stream_t stream) {
+  REQ_PTR(problems);
+  SRK_REQUIRE(count >= 1 && count <= 4 && M > 0, SRK_E_SHAPE, "linear_wgrad_multi: count=%d (1..4), M=%d", count, M);
+  WgradParams ps[4] = {};
+  for (int i = 0; i < count; ++i) {
+    const srk_wgrad_problem& q = problems[i];
+    REQ_PTR(q.y); REQ_PTR(q.x); REQ_PTR(q.dw); REQ_ALIGN(q.y); REQ_ALIGN(q.x);
+    ps[i].Y = static_cast<const bf16_t*>(q.y); ps[i].ldy = q.ldy > 0 ? q.ldy : q.N;
+    ps[i].X = static_cast<const bf16_t*>(q.x); ps[i].ldx = q.ldx > 0 ? q.ldx : q.K;
+    ps[i].M = M; ps[i].N = q.N; ps[i].K = q.K; ps[i].dW = q.dw; ps[i].ldw = q.K; ps[i].db = q.db;
+  }
+  return srk_launch_wgrad_multi(ps, count, (hipStream_t)stream);
+}
+
 int srk_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* y, int B, int H, int W, int CinP, int N,
                      srk_stream_t stream) {
   REQ_PTR(x); REQ_PTR(w); REQ_PTR(y); REQ_ALIGN(x); REQ_ALIGN(w); REQ_ALIGN(y);

@@ -375,6 +375,12 @@ __global__ __launch_bounds__(256) void win256_table_reduce_kernel(const float* _
   atomicAdd(dtable + (long long)i * nH + h, a);
 }
 
+// zero fill of the fp32 accumulation image (a kernel of our own rather than hipMemsetAsync: under hipGraph capture the memset node of this
+// ROCm build did not re-zero the buffer on replays -- the replayed step accumulated onto the previous replay's sums)
+__global__ __launch_bounds__(256) void win256_zero_kernel(float4* __restrict__ p, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // dqkv[t][CA + c] = bf16(dkv32[t][c]), c < 2 CA
 __global__ __launch_bounds__(256) void win256_dkv_cast_kernel(const float* __restrict__ dkv32, bf16_t* __restrict__ dqkv, long long T, int CA,
                                                               int ldq) {
@@ -411,7 +417,7 @@ int launch_bwd(const Win256BwdParams& p, hipStream_t stream) {
 size_t srk_win256_attn_bwd_scratch(int B, int H, int W, int nH, int CA, int table_rows, int overlap) {
   if (B <= 0 || H <= 0 || W <= 0 || nH <= 0) return 0;
   const size_t nwg = (size_t)B * (H / 16) * (W / 16) * nH;
-  size_t bytes = nwg * (size_t)table_rows * sizeof(float);
+  size_t bytes = (nwg * (size_t)table_rows + 3) / 4 * 4 * sizeof(float);       // the accumulation image behind it starts 16-byte aligned
   if (overlap > 0) bytes += (size_t)B * H * W * 2 * CA * sizeof(float);
   return (bytes + 255) / 256 * 256;
 }
@@ -434,13 +440,15 @@ int srk_launch_win256_attn_bwd(const bf16_t* qkv, int ldq, int CA, const float* 
   p.B = B; p.H = H; p.W = W; p.sy = sy; p.sx = sx; p.nWh = H / 16; p.nWw = W / 16; p.nH = nH; p.scale = scale;
   const long long nwin = (long long)B * p.nWh * p.nWw;
   p.tpart = static_cast<float*>(scratch);
-  p.dkv32 = p.tpart + nwin * nH * table_rows;
+  p.dkv32 = p.tpart + (nwin * nH * table_rows + 3) / 4 * 4;
   const long long T = (long long)B * H * W;
   int rc;
   if (overlap > 0) {
-    if (hipMemsetAsync(p.dkv32, 0, (size_t)T * 2 * CA * sizeof(float), stream) != hipSuccess) {
-      srk_set_error("win256 attention backward: hipMemsetAsync failed");
-      return SRK_E_LAUNCH;
+    {
+      const long long n4 = T * 2 * CA / 4;          // CA % 32 == 0; the scratch region is 16-byte aligned (checked below)
+      SRK_REQUIRE(((size_t)p.dkv32 & 15) == 0, SRK_E_ALIGN, "win256 attention backward: scratch is not 16-byte aligned");
+      const int zgrid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+      hipLaunchKernelGGL(win256_zero_kernel, dim3(zgrid), dim3(256), 0, stream, reinterpret_cast<float4*>(p.dkv32), n4);
     }
     rc = launch_bwd<36, true>(p, stream);
     if (rc) return rc;

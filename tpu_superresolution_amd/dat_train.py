@@ -362,12 +362,20 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
     def put(p, g):
         G[pname(p)] = g.reshape(p.shape).contiguous()
 
+    pending = []          # the block's linear weight gradients: queued, then ONE launch for all four (flush_wgrads)
+
     def lin_wgrad(y, x, lin, row_map=None, col_map=None):
-        dw, db = ops.linear_wgrad_bf16(y, x)
-        N, K = lin.weight.shape
-        G[pname(lin.weight)] = _unpack_linear(dw, N, K, row_map, col_map)
-        if lin.bias is not None:
-            G[pname(lin.bias)] = (db[:N] if row_map is None else db[row_map]).contiguous()
+        pending.append((y, x, lin, row_map, col_map))        # y and x must stay untouched until flush_wgrads
+
+    def flush_wgrads():
+        if not pending:
+            return
+        for (y, x, lin, row_map, col_map), (dw, db) in zip(pending, ops.linear_wgrad_multi_bf16([(q[0], q[1]) for q in pending])):
+            N, K = lin.weight.shape
+            G[pname(lin.weight)] = _unpack_linear(dw, N, K, row_map, col_map)
+            if lin.bias is not None:
+                G[pname(lin.bias)] = (db[:N] if row_map is None else db[row_map]).contiguous()
+        pending.clear()
 
     def conv_wgrad(dyb, xb, conv, Bc, Hc, Wc, CinP, NP, r=1, row_map=None):
         dw, db = torch.zeros(NP, 9 * CinP, **f32), torch.zeros(NP, **f32)
@@ -607,6 +615,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                 check(L.srk_chan_apply_mat(dGt.data_ptr(), q_ptr, 3 * CA, dsk2.data_ptr(), k_ptr, 3 * CA, dqkv.data_ptr() + CA * 2, 3 * CA, B, HW, nH, 0, st))
             check(L.srk_lincomb2_bf16(dv_conv.data_ptr(), CA, None, 0, None, None, None, dqkv.data_ptr() + 2 * CA * 2, 3 * CA, T, CA // 8, 0, 1, st))
             lin_wgrad(dqkv, bk["xn1"], at.qkv, row_map=qkv_rows)
+            flush_wgrads()            # before the kernel below overwrites gxb2 (the fc2 gradient's operand when no DropPath copy was made)
             if CP in (64, 128, 192):      # qkv dgrad with the norm1 backward in its epilogue (gx2 += d x, gxb2 = its bf16 copy)
                 dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
                 _gemm(st, _lib.LD_ROWS, _lib.EP_LNBWD, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, outf=gx2, outb=gxb2, ldo=CP,

@@ -274,13 +274,22 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
     def pname(p):
         return names[id(p)]
 
+    pending = []          # the block's linear weight gradients: queued, then ONE launch for all four (flush_wgrads)
+
     def lin_wgrad(y, x, lin, NP, KP, row_map=None, col_map=None, prefix=None):
-        """dW += y^T x, db += colsum(y) in the packed layout -> the nn.Linear's gradient."""
-        dw, db = ops.linear_wgrad_bf16(y, x)
-        N, K = lin.weight.shape
-        G[pname(lin.weight)] = _unpack_linear(dw, N, K, row_map, col_map)
-        if lin.bias is not None:
-            G[pname(lin.bias)] = (db[:N] if row_map is None else db[row_map]).contiguous()
+        """dW += y^T x, db += colsum(y) in the packed layout -> the nn.Linear's gradient (computed at the next flush_wgrads: y and x must
+        stay untouched until then)."""
+        pending.append((y, x, lin, row_map, col_map))
+
+    def flush_wgrads():
+        if not pending:
+            return
+        for (y, x, lin, row_map, col_map), (dw, db) in zip(pending, ops.linear_wgrad_multi_bf16([(q[0], q[1]) for q in pending])):
+            N, K = lin.weight.shape
+            G[pname(lin.weight)] = _unpack_linear(dw, N, K, row_map, col_map)
+            if lin.bias is not None:
+                G[pname(lin.bias)] = (db[:N] if row_map is None else db[row_map]).contiguous()
+        pending.clear()
 
     def conv_wgrad(dyb, xb, conv, Bc, Hc, Wc, CinP, NP, r=1, row_map=None):
         dw = torch.zeros(NP, 9 * CinP, **f32)
@@ -429,6 +438,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                                              dtab.data_ptr(), attn_scratch.data_ptr(), B, H, W, sh, sh, nH, bk["scale"], overlap, st))
             G[pname(tab)] = dtab
             lin_wgrad(dqkv, bk["xn1"], attn_mod.qkv, 3 * CA, CP, row_map=qkv_rows)
+            flush_wgrads()            # before the kernel below overwrites gxb2 (the fc2 gradient's operand when no DropPath copy was made)
             dxn1 = torch.empty(T, CP, **b16)
             if dxc is not None:
                 _gemm(st, _lib.LD_ROWS, _lib.EP_RES_BF16, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, res=dxc, outb=dxn1)

@@ -182,6 +182,28 @@ def linear_wgrad_bf16(y: torch.Tensor, x: torch.Tensor, with_bias: bool = True):
     return dw, db
 
 
+def linear_wgrad_multi_bf16(pairs):
+    """pairs: up to four (y [M][N] bf16, x [M][K] bf16) with the same M (row-major, contiguous or column slices of contiguous rows) ->
+    [(dw [N][K], db [N])] from ONE launch (include/srk.h: srk_linear_wgrad_multi_bf16)."""
+    from ._lib import WgradProblem
+    assert 1 <= len(pairs) <= 4
+    M = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    arr = (WgradProblem * len(pairs))()
+    outs = []
+    for i, (y, x) in enumerate(pairs):
+        assert y.shape[0] == M and x.shape[0] == M and y.stride(1) == 1 and x.stride(1) == 1
+        N, K = y.shape[1], x.shape[1]
+        dw = torch.zeros((N, K), dtype=torch.float32, device=dev)
+        db = torch.zeros((N,), dtype=torch.float32, device=dev)
+        arr[i].y, arr[i].ldy, arr[i].x, arr[i].ldx = y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0)
+        arr[i].dw, arr[i].db, arr[i].N, arr[i].K = dw.data_ptr(), db.data_ptr(), N, K
+        outs.append((dw, db))
+    _bind_wgrad_workspace(dev)
+    check(lib().srk_linear_wgrad_multi_bf16(arr, len(pairs), M, _stream()))
+    return outs
+
+
 def conv3x3_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """x bf16 NHWC [B,H,W,CinP], w bf16 [N, 9*CinP] (tap-major) -> y bf16 NHWC [B,H,W,N]."""
     B, H, W, CinP = x.shape
