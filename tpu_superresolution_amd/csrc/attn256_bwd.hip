@@ -375,12 +375,6 @@ __global__ __launch_bounds__(256) void win256_table_reduce_kernel(const float* _
   atomicAdd(dtable + (long long)i * nH + h, a);
 }
 
-// zero fill of the fp32 accumulation image (a kernel of our own rather than hipMemsetAsync: under hipGraph capture the memset node of this
-// ROCm build did not re-zero the buffer on replays -- the replayed step accumulated onto the previous replay's sums)
-__global__ __launch_bounds__(256) void win256_zero_kernel(float4* __restrict__ p, long long n4) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 // dqkv[t][CA + c] = bf16(dkv32[t][c]), c < 2 CA
 __global__ __launch_bounds__(256) void win256_dkv_cast_kernel(const float* __restrict__ dkv32, bf16_t* __restrict__ dqkv, long long T, int CA,
                                                               int ldq) {
@@ -444,12 +438,8 @@ int srk_launch_win256_attn_bwd(const bf16_t* qkv, int ldq, int CA, const float* 
   const long long T = (long long)B * H * W;
   int rc;
   if (overlap > 0) {
-    {
-      const long long n4 = T * 2 * CA / 4;          // CA % 32 == 0; the scratch region is 16-byte aligned (checked below)
-      SRK_REQUIRE(((size_t)p.dkv32 & 15) == 0, SRK_E_ALIGN, "win256 attention backward: scratch is not 16-byte aligned");
-      const int zgrid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-      hipLaunchKernelGGL(win256_zero_kernel, dim3(zgrid), dim3(256), 0, stream, reinterpret_cast<float4*>(p.dkv32), n4);
-    }
+    rc = srk_launch_zero_f32(p.dkv32, T * 2 * CA, stream);      // (not hipMemsetAsync: see misc.hip, graph replays)
+    if (rc) return rc;
     rc = launch_bwd<36, true>(p, stream);
     if (rc) return rc;
     const long long n4 = T * (2 * CA / 4);

@@ -57,6 +57,7 @@ inline int srk_batch_psnr_chunks(long long per_image) {
 int srk_launch_crop_u8(const unsigned char* pool, const long long* desc, float* out, int B, int patch, hipStream_t stream);
 int srk_launch_batch_psnr(const float* pred, const float* target, float* partial, int B, long long per_image, float max_val,
                           float* psnr, float* psnr_sum, float* abs_sum, hipStream_t stream);
+int srk_launch_zero_f32(float* p, long long n, hipStream_t stream);      // graph-safe zero fill (misc.hip)
 int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream);
 int srk_launch_add_bf16_into_f32(float* a, const bf16_t* b, long long n, hipStream_t stream);
 int srk_launch_cast_f32_bf16(const float* a, bf16_t* out, long long n, hipStream_t stream);

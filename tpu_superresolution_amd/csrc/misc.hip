@@ -1092,6 +1092,28 @@ int srk_launch_smallconv_wgrad(const bf16_t* x, const float* gy, float* dW, floa
   return srk_check_launch("smallconv_wgrad");
 }
 
+// zero fill of n floats (any alignment).  A kernel of our own rather than hipMemsetAsync: under hipGraph capture the memset node of this
+// ROCm build was not re-executed on replays (found through the overlapping-attention backward: a replayed training step accumulated onto
+// the previous replay's sums), so nothing the library zeroes goes through the runtime's memset.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long long n) {
+  const long long head = (4 - (((size_t)p >> 2) & 3)) & 3;      // floats up to the first 16-byte boundary
+  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i0 < head && i0 < n) p[i0] = 0.f;
+  const long long n4 = n > head ? (n - head) / 4 : 0;
+  float4* q = reinterpret_cast<float4*>(p + head);
+  for (long long i = i0; i < n4; i += (long long)gridDim.x * 256) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long tail0 = head + 4 * n4;
+  if (i0 < n - tail0 && tail0 + i0 < n) p[tail0 + i0] = 0.f;
+}
+
+int srk_launch_zero_f32(float* p, long long n, hipStream_t stream) {
+  if (n <= 0) return SRK_OK;
+  SRK_REQUIRE(p != nullptr && ((size_t)p & 3) == 0, SRK_E_NULL, "zero_f32: null or unaligned pointer");
+  const long long blocks = (n / 4 + 255) / 256 + 1;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p, n);
+  return srk_check_launch("zero_f32");
+}
+
 int srk_launch_add_f32_bf16(float* a, const float* b, bf16_t* ab, long long n, hipStream_t stream) {
   SRK_REQUIRE(n % 4 == 0, SRK_E_SHAPE, "add: n %% 4 != 0");
   hipLaunchKernelGGL(add_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a, b, ab, n / 4);

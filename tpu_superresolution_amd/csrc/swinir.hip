@@ -1114,11 +1114,8 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
   for (int seg = seg_begin; seg < seg_end; ++seg) {
     if (seg == 0) {
       // ---------------- reconstruction tail ----------------
-      if (hipMemsetAsync(gstage_w, 0, (size_t)p->packed_elems * 4, st) != hipSuccess ||
-          hipMemsetAsync(gstage_side, 0, (size_t)p->side_floats * 4, st) != hipSuccess) {
-        srk_set_error("backward: hipMemsetAsync failed");
-        return SRK_E_LAUNCH;
-      }
+      RUN(srk_launch_zero_f32(gstage_w, (long long)p->packed_elems, st));        // (not hipMemsetAsync: see misc.hip, graph replays)
+      RUN(srk_launch_zero_f32(gstage_side, (long long)p->side_floats, st));
       const float inv_range = 1.0f / p->cfg.img_range;
       if (p->cfg.upsampler == SRK_UPSAMPLER_PIXELSHUFFLE) {
         int hs = H, wsz = W;
