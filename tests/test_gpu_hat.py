@@ -408,3 +408,29 @@ def test_hat_graphed_train_step_matches_eager_steps():
     ga = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in ma.parameters())))
     gb = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in mb.parameters())))
     assert abs(ga - gb) <= 0.05 * ga, (ga, gb)          # both were clipped to the same norm from nearly the same raw gradients
+
+
+def test_graphed_train_step_draws_fresh_drop_path_factors_every_step():
+    """With drop_path > 0 the graphed step reads its DropPath factors from a static buffer that is re-drawn (eagerly) before every replay:
+    the factors differ from step to step, some are zero, and the steps stay finite and lower the loss."""
+    import tpu_superresolution_amd as T
+    from tpu_superresolution_amd.training import GraphedTrainStep
+    g, cfg, sd = hat_tiny_weights()
+    m = T.HAT(drop_path_rate=0.4, **cfg.kwargs())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.0, capturable=True)
+    gs = GraphedTrainStep(m, opt, max_grad_norm=1.0, warmup=1)
+    torch.manual_seed(3)
+    x, t = torch.rand(2, 3, 32, 32, device="cuda"), torch.rand(2, 3, 128, 128, device="cuda")
+    seen, losses = [], []
+    for _ in range(6):
+        loss, bad = gs(x, t)
+        seen.append(gs.drop.clone())
+        losses.append(float(loss))
+        assert int(bad) == 0
+    assert gs.drop is not None and m._drop_override is gs.drop
+    assert any(not torch.equal(seen[i], seen[i + 1]) for i in range(5)) and any(float(s.min()) == 0.0 for s in seen)
+    assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0], losses
+    gs.close()
+    assert m._drop_override is None

@@ -539,6 +539,16 @@ class HAT(nn.Module):
     def forward_features(self, x):
         raise NotImplementedError("forward_features is part of HAT.forward on the HIP path")
 
+    def draw_drop_path(self, B: int, device) -> Optional[torch.Tensor]:
+        """DropPath factors [n_blocks][2][B] (0 or 1 / keep; hat_arch.py:258 draws them per sample) or None when every rate is 0"""
+        probs = [blk.drop_path_prob for layer in self.layers for blk in layer.residual_group.blocks]
+        if not any(pr > 0 for pr in probs):
+            return None
+        keep = getattr(self, "_keep_cache", None)          # built once per device: a host -> device upload cannot be graph-captured
+        if keep is None or keep.device != torch.device(device):
+            keep = self._keep_cache = 1.0 - torch.tensor(probs, dtype=torch.float32, device=device).view(-1, 1, 1)
+        return (torch.rand(len(probs), 2, B, device=device) < keep).float() / keep
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("this HAT runs on MI355X through libsrk only; move the model and input to the GPU (no CPU fallback)")
@@ -555,12 +565,9 @@ class HAT(nn.Module):
             from .hat_train import HATFunction
             drop = None
             if self.training:
-                probs = [blk.drop_path_prob for layer in self.layers for blk in layer.residual_group.blocks]
-                if any(pr > 0 for pr in probs):
-                    keep = getattr(self, "_keep_cache", None)          # built once per device: a host -> device upload cannot be graph-captured
-                    if keep is None or keep.device != x.device:
-                        keep = self._keep_cache = 1.0 - torch.tensor(probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
-                    drop = (torch.rand(len(probs), 2, x.shape[0], device=x.device) < keep).float() / keep
+                drop = getattr(self, "_drop_override", None)      # training.GraphedTrainStep draws the factors outside its graph
+                if drop is None:
+                    drop = self.draw_drop_path(x.shape[0], x.device)
             return HATFunction.apply(self, x, drop, *[p for _, p in self.named_parameters()])
         with torch.no_grad(), torch.cuda.device(x.device):
             return _hat_forward(self, x.contiguous().float(), self._pack(x.device))

@@ -71,14 +71,16 @@ class GraphedTrainStep:
 
     Requirements: static batch shape, an optimizer constructed with ``capturable=True``, no gradient all-reduce hook on the model
     (world size 1: collectives stay outside graphs here), nothing in the step that reads a device value on the host.  The first call
-    runs ``warmup`` eager steps (kernel attributes, caches and workspaces get set up outside the capture), then captures."""
+    runs ``warmup`` eager steps (kernel attributes, caches and workspaces get set up outside the capture), then captures.  DropPath
+    factors are drawn OUTSIDE the graph, before every replay, into a static buffer the captured forward reads (``model.draw_drop_path``
+    / ``model._drop_override``): a fresh draw per step does not depend on how the graph-captured generator advances."""
 
     def __init__(self, model, optimizer, max_grad_norm: float = 1.0, warmup: int = 2):
         if getattr(model, "grad_sync", None) is not None:
             raise ValueError("GraphedTrainStep: detach the gradient synchronizer (graph capture is for single-process steps)")
         self.model, self.opt, self.max_grad_norm, self.warmup = model, optimizer, float(max_grad_norm), int(warmup)
         self.graph = None
-        self.x = self.t = self.loss = self.bad = None
+        self.x = self.t = self.loss = self.bad = self.drop = None
 
     def _eager(self, x, t):
         self.opt.zero_grad(set_to_none=True)
@@ -89,8 +91,14 @@ class GraphedTrainStep:
         return loss.detach(), bad
 
     def __call__(self, lr_img: torch.Tensor, hr_img: torch.Tensor):
+        draw = getattr(self.model, "draw_drop_path", None)
         if self.graph is None:
             self.x, self.t = lr_img.clone(), hr_img.clone()
+            if draw is not None and self.model.training:
+                d = draw(lr_img.shape[0], lr_img.device)
+                if d is not None:
+                    self.drop = d.clone()
+                    self.model._drop_override = self.drop        # the captured forward reads this buffer
             side = torch.cuda.Stream(device=lr_img.device)
             side.wait_stream(torch.cuda.current_stream(lr_img.device))
             with torch.cuda.stream(side):              # warm-up on a side stream, as torch.cuda.graphs asks
@@ -104,5 +112,12 @@ class GraphedTrainStep:
             raise ValueError(f"GraphedTrainStep was captured for {tuple(self.x.shape)} -> {tuple(self.t.shape)}")
         self.x.copy_(lr_img)
         self.t.copy_(hr_img)
+        if self.drop is not None:
+            self.drop.copy_(draw(lr_img.shape[0], lr_img.device))
         self.graph.replay()
         return self.loss, self.bad
+
+    def close(self) -> None:
+        """Detach from the model (its forward draws its own DropPath factors again)."""
+        if getattr(self.model, "_drop_override", None) is self.drop:
+            self.model._drop_override = None
