@@ -28,6 +28,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import _lib, ops
 from ._lib import check, lib
 from .hat_arch import _pack_conv_T
@@ -39,6 +41,9 @@ EPS = 1e-5
 def _da():
     from . import dat_arch
     return dat_arch
+
+
+_POISON = os.environ.get("SRK_DBG_POISON") == "1"
 
 
 def _ha():
@@ -577,7 +582,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             check(L.srk_dwconv3x3(dcpre.data_ptr(), CA, PT[pre + "dw_wf"].data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, 0, dv_conv.data_ptr(), CA,
                                   B, H, W, CA // 8, 0, st))
             # ---- attention core ----
-            dqkv = torch.zeros(T, 3 * CA, **b16)
+            dqkv = torch.empty(T, 3 * CA, **b16) if not _POISON else torch.full((T, 3 * CA), float("nan"), **b16)      # every element is written by the attention backward
             if bk["spatial"]:
                 for br, (hs, wsz) in enumerate(((s0, s1), (s1, s0))):
                     sa = at.attns[br]

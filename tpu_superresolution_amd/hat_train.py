@@ -26,8 +26,13 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
+import os
+
 from . import _lib, ops
 from ._lib import check, lib
+
+
+_POISON = os.environ.get("SRK_DBG_POISON") == "1"
 
 
 def _ha():
@@ -432,7 +437,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             need = int(L.srk_win256_attention_bwd_scratch(B, H, W, nH, CA, tab.shape[0], overlap))
             if attn_scratch is None or attn_scratch.numel() < need:
                 attn_scratch = torch.empty(need, dtype=torch.uint8, device=dev)
-            dqkv = torch.zeros(T, 3 * CA, **b16)
+            dqkv = torch.empty(T, 3 * CA, **b16) if not _POISON else torch.full((T, 3 * CA), float("nan"), **b16)      # every element is written by the attention backward
             dtab = torch.zeros_like(tab, dtype=torch.float32)
             check(L.srk_win256_attention_bwd(bk["qkv"].data_ptr(), 3 * CA, CA, tab.data_ptr(), tab.shape[0], dao.data_ptr(), CA, dqkv.data_ptr(),
                                              dtab.data_ptr(), attn_scratch.data_ptr(), B, H, W, sh, sh, nH, bk["scale"], overlap, st))
