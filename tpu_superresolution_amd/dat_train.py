@@ -102,6 +102,67 @@ def _channel_attention_matrix(G: torch.Tensor, sq: torch.Tensor, sk: torch.Tenso
     return F.pad(torch.softmax(logits, dim=-1), (0, 32 - dh, 0, 32 - dh))
 
 
+_POS_KEYS = ("pos_proj.weight", "pos_proj.bias", "pos1.0.weight", "pos1.0.bias", "pos1.2.weight", "pos1.2.bias", "pos2.0.weight", "pos2.0.bias",
+             "pos2.2.weight", "pos2.2.bias", "pos3.0.weight", "pos3.0.bias", "pos3.2.weight", "pos3.2.bias")
+
+
+def _pos_mlp_batched(x: torch.Tensor, Pm: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """DynamicPosBias (residual=False, dat_arch.py:93-130) of n position-bias modules at once: x [n][R][2], every parameter stacked along
+    dim 0 -> [n][R][heads].  One batched op per layer instead of one per module and layer (36 modules in DAT x4)."""
+    p = torch.baddbmm(Pm["pos_proj.bias"][:, None, :], x, Pm["pos_proj.weight"].transpose(1, 2))
+    for k in ("pos1", "pos2", "pos3"):
+        p = F.layer_norm(p, (p.shape[-1],)) * Pm[k + ".0.weight"][:, None, :] + Pm[k + ".0.bias"][:, None, :]
+        p = torch.baddbmm(Pm[k + ".2.bias"][:, None, :], F.relu(p), Pm[k + ".2.weight"].transpose(1, 2))
+    return p
+
+
+class _PosBiasGroup:
+    """All Spatial_Attention position-bias modules of a model with the same shapes: their dense biases [n][heads][N][N] from one
+    batched evaluation, and -- after the backward has filled d_bias -- every module's parameter gradients from one batched autograd."""
+
+    def __init__(self, sas):
+        self.sas = sas
+        self.index = {id(sa): i for i, sa in enumerate(sas)}
+        self.rpe = torch.stack([sa.rpe_biases.float() for sa in sas])                               # [n][R][2]
+        self.rpi = torch.stack([sa.relative_position_index.reshape(-1) for sa in sas])              # [n][N * N]
+        self.N = sas[0].H_sp * sas[0].W_sp
+        self.dense = self.d_bias = None
+
+    def stacked(self):
+        mods = [dict(sa.pos.named_parameters()) for sa in self.sas]
+        return {k: torch.stack([mp[k].float() for mp in mods]) for k in _POS_KEYS}
+
+    def forward(self):
+        pos = _pos_mlp_batched(self.rpe, self.stacked())                                            # [n][R][hb]
+        n, hb = pos.shape[0], pos.shape[2]
+        g = pos.gather(1, self.rpi[:, :, None].expand(-1, -1, hb))                                   # [n][N * N][hb]
+        self.dense = g.view(n, self.N, self.N, hb).permute(0, 3, 1, 2).contiguous()
+        return self.dense
+
+    def backward(self, put):
+        n, hb = self.d_bias.shape[0], self.d_bias.shape[1]
+        src = self.d_bias.permute(0, 2, 3, 1).reshape(n, self.N * self.N, hb)
+        dpos = torch.zeros(n, self.rpe.shape[1], hb, dtype=torch.float32, device=src.device)
+        dpos.scatter_add_(1, self.rpi[:, :, None].expand(-1, -1, hb), src)
+        with torch.enable_grad():
+            Pm = {k: v.detach().requires_grad_(True) for k, v in self.stacked().items()}
+            grads = torch.autograd.grad(_pos_mlp_batched(self.rpe, Pm), [Pm[k] for k in _POS_KEYS], dpos, allow_unused=True)
+        for k, gk in zip(_POS_KEYS, grads):
+            for i, sa in enumerate(self.sas):
+                p_ = dict(sa.pos.named_parameters())[k]
+                put(p_, gk[i] if gk is not None else torch.zeros_like(p_))
+
+
+def _pos_groups(m):
+    groups: Dict[tuple, list] = {}
+    for layer in m.layers:
+        for blk in layer.blocks:
+            if hasattr(blk.attn, "attns"):
+                for sa in blk.attn.attns:
+                    groups.setdefault((sa.num_heads, sa.H_sp * sa.W_sp, sa.rpe_biases.shape[0], sa.pos.pos_dim), []).append(sa)
+    return [_PosBiasGroup(v) for v in groups.values()]
+
+
 def _dense_bias(sa) -> torch.Tensor:
     """DynamicPosBias MLP on the offset table, gathered into [heads][N][N] (dat_arch.py:219-224)"""
     pos = sa.pos(sa.rpe_biases.float())
@@ -192,6 +253,16 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
     _, cur, mean_pe, rstd_pe = ops.layernorm_fwd(f0, m.before_RG[1].weight, m.before_RG[1].bias, C_, out_bf16=False, out_f32=True)
     S.update(img4=img4, f0=f0, mean_pe=mean_pe, rstd_pe=rstd_pe)
 
+    # the dense position biases of every spatial block, from one batched evaluation of the position-bias MLPs
+    pos_groups = _pos_groups(m)
+    pos_of = {}
+    for gq in pos_groups:
+        dense = gq.forward()
+        gq.d_bias = None
+        for sa in gq.sas:
+            pos_of[id(sa)] = (gq, gq.index[id(sa)])
+    S["pos_groups"], S["pos_of"] = pos_groups, pos_of
+
     n_chunks = int(L.srk_chan_stats_chunks(HW))
 
     def token_sums(p, ldp, q, ldq, C8, per_sample=False):
@@ -233,7 +304,8 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
                 for br, (hs, wsz) in enumerate(((s0, s1), (s1, s0))):
                     sy, sx = (hs // 2, wsz // 2) if at.shifted else (0, 0)
                     off = br * hb * 32 * 2
-                    bias = _dense_bias(at.attns[br])
+                    gq, gi = pos_of[id(at.attns[br])]
+                    bias = gq.dense[gi]
                     biases.append(bias)
                     check(L.srk_win_attention_fwd_padded(qkv.data_ptr() + off, 3 * CA, CA, bias.data_ptr(), 0, att.data_ptr() + off, CA, B, H, W, Hp,
                                                          Wp, hs, wsz, sy, sx, hb, scale, 0, st))
@@ -589,20 +661,16 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                     sy, sx = (hs // 2, wsz // 2) if at.shifted else (0, 0)
                     off = br * hb * 32 * 2
                     N = hs * wsz
-                    dbias = torch.zeros(hb, N, N, **f32)
+                    gq, gi = S["pos_of"][id(sa)]
+                    if gq.d_bias is None:
+                        gq.d_bias = torch.zeros_like(gq.dense)
+                    dbias = gq.d_bias[gi]                                 # accumulated in place; the MLPs' backward runs once, at the end
                     need = int(L.srk_win_attention_bwd_padded_scratch(B, Hp, Wp, hs, wsz, hb))
                     if attn_scratch is None or attn_scratch.numel() < need:
                         attn_scratch = torch.empty(need, dtype=torch.uint8, device=dev)
                     check(L.srk_win_attention_bwd_padded(qkv.data_ptr() + off, 3 * CA, CA, bk["biases"][br].data_ptr(), d_att.data_ptr() + off, CA,
                                                          dqkv.data_ptr() + off, dbias.data_ptr(), attn_scratch.data_ptr(), B, H, W, Hp, Wp, hs, wsz, sy,
                                                          sx, hb, bk["scale"], st))
-                    R = sa.rpe_biases.shape[0]
-                    dpos = torch.zeros(R, hb, **f32).index_add_(0, sa.relative_position_index.reshape(-1), dbias.permute(1, 2, 0).reshape(N * N, hb))
-                    pos_params = list(sa.pos.parameters())
-                    with torch.enable_grad():
-                        grads = torch.autograd.grad(sa.pos(sa.rpe_biases.float()), pos_params, dpos, allow_unused=True)
-                    for p_, g_ in zip(pos_params, grads):
-                        put(p_, g_ if g_ is not None else torch.zeros_like(p_))
             else:
                 part = torch.empty(int(L.srk_chan_gram_floats(B, HW, nH)), **f32)
                 check(L.srk_chan_gram(d_att.data_ptr(), CA, v_ptr, 3 * CA, part.data_ptr(), B, HW, nH, st))
@@ -633,6 +701,9 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
         check(L.srk_add_f32_bf16(gx.data_ptr(), gx2.data_ptr(), gxb.data_ptr(), T * CP, st))      # d(layer input) = d(body input) + d(layer output)
         segment_done()
 
+    for gq in S["pos_groups"]:            # every position-bias MLP's parameter gradients from one batched backward
+        if gq.d_bias is not None:
+            gq.backward(put)
     # ---------------- head: before_RG's LayerNorm, long skip, conv_first ----------------
     gf = torch.empty(T, CP, **f32)
     ln_bwd(gxb, S["f0"], S["mean_pe"], S["rstd_pe"], m.before_RG[1], gf, None, accumulate=False)
