@@ -400,6 +400,17 @@ int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const flo
 int64_t srk_chan_stats_chunks(int64_t rows_per_sample);
 int srk_chan_stats(const uint16_t* p, int ldp, const uint16_t* q, int ldq, float* partial, int samples, int64_t rows_per_sample, int C8,
                    srk_stream_t stream);
+/* nn.BatchNorm2d in training mode between two token passes (dat_arch.py:301-313, :464-476), one launch each:
+ *   srk_bn_train_coeffs: the R partial rows (row_stride floats apart; sum x at + 0, sum x^2 at + ld; from srk_chan_stats or
+ *     srk_spatial_gate_train what 0) summed in a fixed order -> coef [4][ld] = scale (gamma rstd), shift (beta - mean scale), mean, rstd over n values per channel; running_mean / running_var
+ *     (or null) move in place by `momentum` with the unbiased variance; real_of[c] = index of channel c in the module's un-padded buffers,
+ *     -1 for padding (null: identity).
+ *   srk_bn_train_bwd_coeffs: partial rows (sum dz, sum dz x) + the forward's coef -> coef [5][ld] = A, B, C of d x = A dz + B x + C,
+ *     d gamma, d beta. */
+int srk_bn_train_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* gamma, const float* beta, float eps, float* coef,
+                        float* running_mean, float* running_var, float momentum, const int* real_of, srk_stream_t stream);
+int srk_bn_train_bwd_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* fwd_coef, float* coef,
+                            srk_stream_t stream);
 /* out = act(x * scale[i][c] + shift[i][c]); i = row / rows_per_sample (rows_per_sample 0: one vector for all rows); act 1 = GELU */
 int srk_affine_act_bf16(const uint16_t* x, int ldx, const float* scale, const float* shift, uint16_t* out, int ldo, int64_t rows, int C8,
                         int rows_per_sample, int act, srk_stream_t stream);

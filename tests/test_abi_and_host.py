@@ -207,5 +207,5 @@ def test_batched_weight_packing_equals_one_tensor_at_a_time():
         reset(s, "_w16_packed")
         return dict(swinir_w16.pack(s, dev))
 
-    assert both(hat_p) == 93 and both(hat_pt) == 37 and both(dat_p(False)) == 131 and both(dat_p(True)) == 73 and both(dat_pt) == 48
+    assert both(hat_p) == 93 and both(hat_pt) == 37 and both(dat_p(False)) == 131 and both(dat_p(True)) == 73 and both(dat_pt) == 58
     assert both(w16_p) == 45

@@ -301,12 +301,29 @@ def test_dat_spatial_gate_train_passes_vs_autograd():
     ps = part.sum(0)
     s_, t_, mu, rstd, var = DT._bn_coeffs(ps[0, :S], ps[1, :S], T, gam.cuda(), bet.cuda())
     assert _rel(mu.cpu(), y1.detach().mean(0)) <= 1e-4 and _rel(var.cpu(), y1.detach().var(0, unbiased=False)) <= 1e-4
+    # the one-launch coefficient kernel against the closed form above, running buffers against nn.BatchNorm's own update
+    gd, bd = gam.cuda(), bet.cuda()
+    coef = torch.full((4, 16), 7.0, device="cuda")
+    rm, rv = torch.randn(S, generator=g).cuda(), (torch.rand(S, generator=g) + 0.5).cuda()
+    bn_ref = torch.nn.BatchNorm1d(S, momentum=0.1)
+    bn_ref.running_mean.copy_(rm.cpu()); bn_ref.running_var.copy_(rv.cpu())
+    bn_ref.train()(y1.detach())
+    check(L.srk_bn_train_coeffs(part.data_ptr(), nblk, 32, 16, S, float(T), gd.data_ptr(), bd.data_ptr(), 1e-5, coef.data_ptr(), rm.data_ptr(),
+                                rv.data_ptr(), 0.1, None, _st()))
+    for row, want in enumerate((s_, t_, mu, rstd)):
+        assert _rel(coef[row, :S].cpu(), want.cpu()) <= 1e-5, row
+    assert _rel(rm.cpu(), bn_ref.running_mean) <= 1e-4 and _rel(rv.cpu(), bn_ref.running_var) <= 1e-4
+    fwd_coef = coef
     part = torch.empty(nblk, 4, 16, device="cuda")
     check(L.srk_spatial_gate_train(1, xd.data_ptr(), CA, W0d.data_ptr(), b0d.data_ptr(), s_.data_ptr(), t_.data_ptr(), w3d.data_ptr(), dsd.data_ptr(),
                                    None, None, None, None, 0, 0, part.data_ptr(), T, CA, S, _st()))
     ps = part.sum(0)
     cA, cB, cC, dgam, dbet = (v.contiguous() for v in DT._bn_backward_coeffs(ps[0, :S], ps[1, :S], T, s_, mu, rstd))
     assert _rel(dgam.cpu(), gr.grad) <= 1e-3 and _rel(dbet.cpu(), br.grad) <= 1e-3 and _rel(ps[2, :S].cpu(), w3r.grad) <= 1e-3
+    bc = torch.full((5, 16), 7.0, device="cuda")
+    check(L.srk_bn_train_bwd_coeffs(part.data_ptr(), nblk, 64, 16, S, float(T), fwd_coef.data_ptr(), bc.data_ptr(), _st()))
+    for row, want in enumerate((cA, cB, cC, dgam, dbet)):
+        assert _rel(bc[row, :S].cpu(), want.cpu()) <= 1e-4, row
     assert abs(float(ps[3, 0]) - float(dsm.sum())) <= 1e-3
     dx = torch.zeros(T, CA, dtype=torch.bfloat16, device="cuda")
     part = torch.empty(nblk, 16, CA + 1, device="cuda")

@@ -83,6 +83,78 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const bf16_t* __restric
   }
 }
 
+// Sum of the R partial rows for 64 channels per workgroup: thread = (row group rg of 4, channel), eight independent loads in flight per
+// thread (one dependent add per load made this a chain of R memory round trips), row groups combined through LDS in a fixed order.
+// Returns the channel of this thread when it holds the sums (rg == 0 and c < Cn), else -1.
+__device__ __forceinline__ int bn_sum_rows(const float* __restrict__ partial, int R, int rs, int ld, int Cn, float& s1, float& s2) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < Cn) {
+    const float* base = partial + c;
+    int r = rg;
+    for (; r + 28 < R; r += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a1[u] += base[(long long)(r + 4 * u) * rs];
+        a2[u] += base[(long long)(r + 4 * u) * rs + ld];
+      }
+    }
+    for (; r < R; r += 4) {
+      a1[0] += base[(long long)r * rs];
+      a2[0] += base[(long long)r * rs + ld];
+    }
+  }
+  red[0][rg][cl] = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+  red[1][rg][cl] = ((a2[0] + a2[1]) + (a2[2] + a2[3])) + ((a2[4] + a2[5]) + (a2[6] + a2[7]));
+  __syncthreads();
+  s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  return (rg == 0 && c < Cn) ? c : -1;
+}
+
+// BatchNorm (training) between two token passes, one thread per channel: the R partial rows (rs floats apart; the two sums at + 0 and + ld)
+// of chan_stats / spatial_gate_train are summed in a fixed order, then  mean = s1 / n, var = s2 / n - mean^2, rstd = (var + eps)^-1/2, scale = gamma rstd, shift = beta - mean scale
+// -> coef [4][ld] = scale, shift, mean, rstd; the running estimates move in place as nn.BatchNorm2d's do (momentum, unbiased variance);
+// real_of[c] = index of padded channel c in the BatchNorm's own (un-padded) buffers, -1 for padding (null: identity).
+__global__ __launch_bounds__(256) void bn_train_coeffs_kernel(const float* __restrict__ partial, int R, int rs, int ld, int Cn, float n,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ coef, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum, const int* __restrict__ real_of) {
+  float s1, s2;
+  const int c = bn_sum_rows(partial, R, rs, ld, Cn, s1, s2);
+  if (c < 0) return;
+  const float mean = s1 / n;
+  const float var = fmaxf(s2 / n - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * rstd;
+  coef[c] = sc;
+  coef[ld + c] = beta[c] - mean * sc;
+  coef[2 * ld + c] = mean;
+  coef[3 * ld + c] = rstd;
+  const int rc = real_of ? real_of[c] : c;
+  if (running_mean != nullptr && rc >= 0) {
+    running_mean[rc] = (1.0f - momentum) * running_mean[rc] + momentum * mean;
+    running_var[rc] = (1.0f - momentum) * running_var[rc] + momentum * var * (n / fmaxf(n - 1.0f, 1.0f));
+  }
+}
+
+// ... and its backward: S1 = sum dz, S2 = sum dz x (partial rows as above) -> coef [5][ld] = A, B, C of d x = A dz + B x + C, d gamma, d beta
+__global__ __launch_bounds__(256) void bn_train_bwd_coeffs_kernel(const float* __restrict__ partial, int R, int rs, int ld, int Cn, float n,
+                                                                  const float* __restrict__ fwd_coef, float* __restrict__ coef) {
+  float S1, S2;
+  const int c = bn_sum_rows(partial, R, rs, ld, Cn, S1, S2);
+  if (c < 0) return;
+  const float sc = fwd_coef[c], mean = fwd_coef[2 * ld + c], rstd = fwd_coef[3 * ld + c];
+  const float dgamma = rstd * (S2 - mean * S1);
+  coef[c] = sc;
+  coef[ld + c] = -sc * rstd * dgamma / n;
+  coef[2 * ld + c] = (sc / n) * (mean * rstd * dgamma - S1);
+  coef[3 * ld + c] = dgamma;
+  coef[4 * ld + c] = S1;
+}
+
 // coefficient index of row t, channel c: (rps > 0 ? t / rps : 0) * CP + c
 template <int MODE>      // 0 affine (+ optional GELU), 1 dgelu_affine, 2 lincomb2
 __global__ __launch_bounds__(256) void token_elementwise_kernel(const bf16_t* __restrict__ p, int ldp, const bf16_t* __restrict__ q, int ldq,
@@ -663,6 +735,25 @@ int srk_launch_win_attn_bwd_padded(const bf16_t* qkv, int ldq, int CA, const flo
 extern "C" {
 
 #define REQP(c, ...) SRK_REQUIRE(c, SRK_E_SHAPE, __VA_ARGS__)
+
+int srk_bn_train_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* gamma, const float* beta, float eps, float* coef,
+                        float* running_mean, float* running_var, float momentum, const int* real_of, srk_stream_t stream) {
+  SRK_REQUIRE(partial && gamma && beta && coef, SRK_E_NULL, "bn_train_coeffs: null pointer");
+  REQP(R > 0 && C > 0 && C <= ld && row_stride >= 2 * ld && n > 0.f && (running_mean == nullptr) == (running_var == nullptr),
+       "bn_train_coeffs: bad shape");
+  hipLaunchKernelGGL(bn_train_coeffs_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, R, row_stride, ld, C, n, gamma, beta, eps, coef,
+                     running_mean, running_var, momentum, real_of);
+  return srk_check_launch("bn_train_coeffs");
+}
+
+int srk_bn_train_bwd_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* fwd_coef, float* coef,
+                            srk_stream_t stream) {
+  SRK_REQUIRE(partial && fwd_coef && coef, SRK_E_NULL, "bn_train_bwd_coeffs: null pointer");
+  REQP(R > 0 && C > 0 && C <= ld && row_stride >= 2 * ld && n > 0.f, "bn_train_bwd_coeffs: bad shape");
+  hipLaunchKernelGGL(bn_train_bwd_coeffs_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, R, row_stride, ld, C, n, fwd_coef,
+                     coef);
+  return srk_check_launch("bn_train_bwd_coeffs");
+}
 
 int64_t srk_chan_stats_chunks(int64_t rows) { return rows <= 0 ? 0 : (rows + ST_ROWS - 1) / ST_ROWS; }
 

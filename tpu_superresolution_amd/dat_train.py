@@ -69,6 +69,29 @@ def _bn_backward_coeffs(S1: torch.Tensor, S2: torch.Tensor, n: int, s: torch.Ten
     return s, Bc, Cc, dgamma, S1
 
 
+def _bn_forward(L, st, part: torch.Tensor, R: int, row_stride: int, ld: int, Cn: int, n: int, gamma: torch.Tensor, beta: torch.Tensor,
+                bn: nn.BatchNorm2d, real_of: Optional[torch.Tensor]) -> torch.Tensor:
+    """partial sums -> coef [4][ld] = scale, shift, mean, rstd in ONE launch (srk_bn_train_coeffs), running buffers moved in place"""
+    coef = torch.empty(4, ld, dtype=torch.float32, device=part.device)
+    track = bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None and bn.running_mean.dtype == torch.float32
+    check(L.srk_bn_train_coeffs(part.data_ptr(), R, row_stride, ld, Cn, float(n), gamma.data_ptr(), beta.data_ptr(), float(bn.eps), coef.data_ptr(),
+                                bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                float(bn.momentum) if track else 0.0, None if real_of is None else real_of.data_ptr(), st))
+    if track:
+        bn.num_batches_tracked += 1
+    elif bn.track_running_stats and bn.running_mean is not None:      # momentum None (cumulative average) / other dtypes: the torch path
+        cm = coef[2, :Cn] if real_of is None else coef[2][real_of_inverse(real_of)]
+        rs = coef[3, :Cn] if real_of is None else coef[3][real_of_inverse(real_of)]
+        _bn_update(bn, cm, (1.0 / (rs * rs) - bn.eps).clamp_min(0.0), n)
+    return coef
+
+
+def real_of_inverse(real_of: torch.Tensor) -> torch.Tensor:
+    """padded position of every real channel (the positions where real_of >= 0, ordered by the real index)"""
+    pos = torch.nonzero(real_of >= 0).flatten()
+    return pos[torch.argsort(real_of[pos])]
+
+
 def _bn_update(bn: nn.BatchNorm2d, mean: torch.Tensor, var: torch.Tensor, n: int) -> None:
     """nn.BatchNorm2d's buffer update in training (momentum None = cumulative average, as torch)"""
     if not bn.track_running_stats or bn.running_mean is None:
@@ -200,6 +223,8 @@ def pack_train(m, device) -> Dict[str, torch.Tensor]:
                 w9[hm] = at.dwconv[0].weight.float().reshape(C_, 9)
                 P[pre + "dw_wf"] = w9.flip(1).contiguous()                         # the depth-wise dgrad: the same conv with flipped taps
                 P[pre + "dw_b"] = ha._pack_vec(at.dwconv[0].bias, CA, row_map=hm)
+                P[pre + "dw_gam"] = ha._pack_vec(at.dwconv[1].weight, CA, row_map=hm)          # BatchNorm affine in the head-padded layout
+                P[pre + "dw_bet"] = ha._pack_vec(at.dwconv[1].bias, CA, row_map=hm)
                 sg9 = torch.zeros(HPh, 9, device=device)
                 sg9[:half] = blk.ffn.sg.conv.weight.float().reshape(half, 9)
                 P[pre + "sg_wf"] = sg9.flip(1).contiguous()
@@ -291,13 +316,14 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
             c_pre, conv = torch.empty(T, CA, **b16), torch.empty(T, CA, **b16)
             check(L.srk_dwconv3x3(v_ptr, 3 * CA, P[pre + "dw_w"].data_ptr(), ones.data_ptr(), PT[pre + "dw_b"].data_ptr(), None, 0, c_pre.data_ptr(),
                                   CA, B, H, W, CA // 8, 0, st))
-            s1_, s2_ = token_sums(c_pre.data_ptr(), CA, c_pre.data_ptr(), CA, CA // 8)
-            bn = at.dwconv[1]
-            gam, bet = ha._pack_vec(bn.weight, CA, row_map=hm), ha._pack_vec(bn.bias, CA, row_map=hm)
-            dw_s, dw_t, mu, rstd, var = _bn_coeffs(s1_, s2_, T, gam, bet)
-            _bn_update(bn, mu[hm], var[hm], T)
+            part = torch.empty(B, n_chunks, 2, CA, **f32)
+            check(L.srk_chan_stats(c_pre.data_ptr(), CA, c_pre.data_ptr(), CA, part.data_ptr(), B, HW, CA // 8, st))
+            real_of = ha._cached_map(("real_of", nH, dh, str(dev)), lambda: torch.full((CA,), -1, dtype=torch.int32, device=dev).scatter_(
+                0, hm, torch.arange(C_, dtype=torch.int32, device=dev)))
+            dw_coef = _bn_forward(L, st, part, B * n_chunks, 2 * CA, CA, CA, T, PT[pre + "dw_gam"], PT[pre + "dw_bet"], at.dwconv[1], real_of)
+            dw_s, dw_t = dw_coef[0], dw_coef[1]
             check(L.srk_affine_act_bf16(c_pre.data_ptr(), CA, dw_s.data_ptr(), dw_t.data_ptr(), conv.data_ptr(), CA, T, CA // 8, 0, 1, st))
-            bk.update(dw_s=dw_s, dw_t=dw_t, dw_mu=mu, dw_rstd=rstd)
+            bk.update(dw_s=dw_s, dw_t=dw_t, dw_coef=dw_coef)
             att = torch.empty(T, CA, **b16)
             if bk["spatial"]:
                 biases = []
@@ -336,9 +362,8 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
             w0raw, b0raw = PT[pre + "si_w0raw"], si[0].bias.float().contiguous()
             check(L.srk_spatial_gate_train(0, tok_src.data_ptr(), CA, w0raw.data_ptr(), b0raw.data_ptr(), None, None, None, None, None, None, None,
                                            None, 0, 0, part.data_ptr(), T, CA, S2, st))
-            ps = part.sum(0)
-            si_s, si_t, si_mu, si_rstd, si_var = _bn_coeffs(ps[0, :S2], ps[1, :S2], T, si[1].weight.float(), si[1].bias.float())
-            _bn_update(si[1], si_mu, si_var, T)
+            si_coef = _bn_forward(L, st, part, nblk, 32, 16, S2, T, si[1].weight.float(), si[1].bias.float(), si[1], None)
+            si_s, si_t = si_coef[0, :S2], si_coef[1, :S2]
             tgate = torch.empty(T, **f32)
             w3 = si[3].weight.float().reshape(S2).contiguous()
             w0f, b0f = (w0raw * si_s[:, None]).contiguous(), (b0raw * si_s + si_t).contiguous()          # BatchNorm folded for the forward kernel
@@ -366,7 +391,7 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
             _gemm(st, _lib.LD_ROWS, _lib.EP_RES, gated, P[pre + "W2"], T, CP, HPh, lda=HPh, bias=P[pre + "b2"], res=x1, outf=nxt, outb=xb,
                   rowscale=None if drop is None else drop[bidx, 1], rows_per_sample=HW)
             bk.update(xn1=xn1, qkv=qkv, c_pre=c_pre, conv=conv, att=att, cgate=cgate, tgate=tgate, pm=pm, comb=comb, x1=x1, xn2=xn2, u=u, hh=hh,
-                      x2n=x2n, gated=gated, si_s=si_s, si_t=si_t, si_mu=si_mu, si_rstd=si_rstd)
+                      x2n=x2n, gated=gated, si_coef=si_coef)
             S["blocks"].append(bk)
             cur = nxt
             bidx += 1
@@ -619,14 +644,17 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             nblk = (T + 255) // 256
             w0raw, b0raw = PT[pre + "si_w0raw"], si[0].bias.float().contiguous()
             w3 = si[3].weight.float().reshape(S2).contiguous()
-            si_s, si_t = bk["si_s"].contiguous(), bk["si_t"].contiguous()
+            si_coef = bk["si_coef"]
+            si_s, si_t = si_coef[0], si_coef[1]              # 16-entry rows, the first S2 valid
             part = torch.empty(nblk, 4, 16, **f32)
             check(L.srk_spatial_gate_train(1, tok_src.data_ptr(), CA, w0raw.data_ptr(), b0raw.data_ptr(), si_s.data_ptr(), si_t.data_ptr(), w3.data_ptr(),
                                            dsmap.data_ptr(), None, None, None, None, 0, 0, part.data_ptr(), T, CA, S2, st))
             ps = part.sum(0)
-            cA, cB, cC, dgam, dbet = (t.contiguous() for t in _bn_backward_coeffs(ps[0, :S2], ps[1, :S2], T, si_s, bk["si_mu"], bk["si_rstd"]))
-            put(si[1].weight, dgam)
-            put(si[1].bias, dbet)
+            bc = torch.empty(5, 16, **f32)
+            check(L.srk_bn_train_bwd_coeffs(part.data_ptr(), nblk, 64, 16, S2, float(T), si_coef.data_ptr(), bc.data_ptr(), st))
+            cA, cB, cC = bc[0], bc[1], bc[2]
+            put(si[1].weight, bc[3, :S2])
+            put(si[1].bias, bc[4, :S2])
             put(si[3].weight, ps[2, :S2])
             put(si[3].bias, ps[3, :1])
             part = torch.empty(nblk, 16, CA + 1, **f32)
@@ -642,10 +670,13 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             dz = torch.empty(T, CA, **b16)
             check(L.srk_dgelu_affine_bf16(d_conv.data_ptr(), CA, c_pre.data_ptr(), CA, bk["dw_s"].data_ptr(), bk["dw_t"].data_ptr(), dz.data_ptr(), CA, T,
                                           CA // 8, st))
-            S1, S2_ = token_sums(dz.data_ptr(), CA, c_pre.data_ptr(), CA, CA // 8)
-            cA, cB, cC, dgam, dbet = (t.contiguous() for t in _bn_backward_coeffs(S1, S2_, T, bk["dw_s"], bk["dw_mu"], bk["dw_rstd"]))
-            put(at.dwconv[1].weight, dgam[hm])
-            put(at.dwconv[1].bias, dbet[hm])
+            part = torch.empty(B, n_chunks, 2, CA, **f32)
+            check(L.srk_chan_stats(dz.data_ptr(), CA, c_pre.data_ptr(), CA, part.data_ptr(), B, HW, CA // 8, st))
+            bc = torch.empty(5, CA, **f32)
+            check(L.srk_bn_train_bwd_coeffs(part.data_ptr(), B * n_chunks, 2 * CA, CA, CA, float(T), bk["dw_coef"].data_ptr(), bc.data_ptr(), st))
+            cA, cB, cC = bc[0], bc[1], bc[2]
+            put(at.dwconv[1].weight, bc[3][hm])
+            put(at.dwconv[1].bias, bc[4][hm])
             dcpre = d_conv                                          # (re-used buffer)
             check(L.srk_lincomb2_bf16(dz.data_ptr(), CA, c_pre.data_ptr(), CA, cA.data_ptr(), cB.data_ptr(), cC.data_ptr(), dcpre.data_ptr(), CA, T,
                                       CA // 8, 0, 0, st))
