@@ -132,6 +132,10 @@ int srk_probe_end(double* total_ms, double* flops, double* bytes, int* launches)
  *   registers) or the layer-per-launch path.
  *   "mlp_bwd_fused" 1 (default) / 0: the MLP half of a Swin block's backward as one kernel (csrc/gemm_stream.hip: fc2 dgrad, GELU',
  *   fc1 dgrad and the norm2 backward; d u stays on the CU between the two GEMMs) or the two streaming GEMMs.
+ *   "mlp_dgelu_store" 1 (default) / 0: between the fused MLP forward and the fused MLP backward of a training plan the u buffer
+ *   carries bf16(gelu'(u)) instead of bf16(u) (the backward's only use of u; its front waves then multiply instead of evaluating
+ *   erf + exp per element).  Read by the training forward; changing "mlp_bwd_fused" / "gemm_stream" between that forward and its
+ *   backward is then an error (SRK_E_UNSUPPORTED).  The forward's outputs do not depend on it.
  *   "attn_bwd_fused" 1 (default) / 0: attention backward with q/k/v re-projected from the saved norm1 output and the output-
  *   projection dgrad folded in (csrc/attn_bwd_fused.hip; classical width; the training forward then stores no q/k/v), or the
  *   dgrad GEMM + csrc/attn.hip on q/k/v saved by the forward.  Read when a training forward lays out its workspace.

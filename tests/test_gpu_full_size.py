@@ -158,18 +158,28 @@ def test_use_checkpoint_recomputes_and_gives_the_same_gradients(cfg3, batch):
     x = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(41)).cuda()
     t = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(42)).cuda()
     ds = ((torch.rand(36, 2, batch, generator=torch.Generator().manual_seed(43)) < 0.85).float() / 0.85).cuda()
+    from tpu_superresolution_amd._lib import check, lib
     out = {}
-    for ck in (False, True):
-        m = T.SwinIR(drop_path_rate=0.1, use_checkpoint=ck, **cfg.kwargs())
-        m.load_state_dict(sd, strict=True)
-        m = m.cuda().train()
-        loss = torch.nn.functional.l1_loss(m(x, drop_scale=ds), t)
-        loss.backward()
-        out[ck] = (float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()}, m._engine.workspace.numel())
-    assert out[True][0] == out[False][0]
+    # the un-checkpointed step keeps bf16(gelu'(u)) between its fused MLP kernels by default, the checkpointed one refills bf16(u):
+    # same math only with that option off; the default is compared at the bf16 noise of that one rounding
+    for key, ck, dg in (("plain", False, 0), ("ckpt", True, 0), ("plain_default", False, 1)):
+        check(lib().srk_set_option(b"mlp_dgelu_store", dg))
+        try:
+            m = T.SwinIR(drop_path_rate=0.1, use_checkpoint=ck, **cfg.kwargs())
+            m.load_state_dict(sd, strict=True)
+            m = m.cuda().train()
+            loss = torch.nn.functional.l1_loss(m(x, drop_scale=ds), t)
+            loss.backward()
+            out[key] = (float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()}, m._engine.workspace.numel())
+        finally:
+            check(lib().srk_set_option(b"mlp_dgelu_store", 1))
+    out[True], out[False] = out["ckpt"], out["plain"]
+    assert out[True][0] == out[False][0] == out["plain_default"][0]
     for n, g in out[False][1].items():
         rel = float((out[True][1][n] - g).norm() / (g.norm() + 1e-20))
         assert rel <= 1e-5, (n, rel)
+        rel = float((out["plain_default"][1][n] - g).norm() / (g.norm() + 1e-20))
+        assert rel <= 5e-3, (n, rel)
     T_tok = batch * 64 * 64
     saved = out[False][2] - out[True][2]
     assert saved >= 35 * T_tok * (192 + 384 + 384) * 2 * 0.95, (out[False][2], out[True][2])       # 35 of 36 ao + u + h sets, minus the scratch row buffer

@@ -293,6 +293,7 @@ def test_fused_mlp_matches_separate_fc1_fc2_kernels(bs, drop):
         keep = 1.0 - torch.linspace(0, 0.3, 4).view(4, 1, 1)
         ds = ((torch.rand(4, 2, bs, generator=gen) < keep).float() / keep).cuda()
     res = {}
+    check(lib().srk_set_option(b"mlp_dgelu_store", 0))        # the default keeps gelu'(u) in the u buffer: see the test below
     try:
         for on in (1, 0):
             check(lib().srk_set_option(b"mlp_fused", on))
@@ -308,6 +309,7 @@ def test_fused_mlp_matches_separate_fc1_fc2_kernels(bs, drop):
             res[on] = (out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}, u.cpu(), h.cpu(), y_inf.cpu())
     finally:
         check(lib().srk_set_option(b"mlp_fused", 1))
+        check(lib().srk_set_option(b"mlp_dgelu_store", 1))
     assert torch.isfinite(res[1][0]).all()
     assert torch.equal(res[1][2].view(torch.int16), res[0][2].view(torch.int16)), "u differs"
     assert torch.equal(res[1][3].view(torch.int16), res[0][3].view(torch.int16)), "h differs"
@@ -316,6 +318,39 @@ def test_fused_mlp_matches_separate_fc1_fc2_kernels(bs, drop):
     for n in res[0][1]:
         rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
         assert rel <= 1e-4, f"{n}: {rel:.3e}"            # bias / LayerNorm gradients use fp32 atomics (order-dependent last bits)
+
+
+def test_fused_mlp_pair_keeps_gelu_derivative_between_the_passes():
+    """Default of the training plan (option mlp_dgelu_store = 1): the fused MLP forward stores gelu'(u) where the separate kernels
+    store u, and the fused MLP backward multiplies by it instead of evaluating erf + exp per element.  The stored tile equals
+    bf16(gelu'(u)) up to one bf16 step (u is rounded to bf16 in the other variant, gelu' in this one), the forward outputs are
+    bit-identical, and the gradients agree to the bf16 noise of that one rounding."""
+    from tpu_superresolution_amd._lib import check, lib
+    cfg = _mid_cfg()
+    sd = O.random_state_dict(cfg, seed=13, scale=1.0)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand(4, 3, 64, 64, generator=gen).cuda()
+    t = torch.rand(4, 3, 128, 128, generator=gen).cuda()
+    res = {}
+    try:
+        for on in (1, 0):
+            check(lib().srk_set_option(b"mlp_dgelu_store", on))
+            m = build(cfg, sd, train=True)
+            out = m(x)
+            torch.nn.functional.l1_loss(out, t).backward()
+            torch.cuda.synchronize()
+            u = m._engine.activation("blk1.u", torch.bfloat16).float().cpu()
+            res[on] = (out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}, u)
+    finally:
+        check(lib().srk_set_option(b"mlp_dgelu_store", 1))
+    assert torch.equal(res[1][0], res[0][0])
+    u = res[0][2].double()
+    want = 0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-u * u / 2) / (2 * torch.pi) ** 0.5
+    assert float((res[1][2].double() - want).abs().max()) <= 2.0 ** -7, "stored gelu'(u)"     # |gelu''| <= 0.8, |u| 2^-9 + one bf16 step of a value <= 1.13
+    assert float((res[1][2].double() - want).abs().mean()) <= 2e-3
+    for n in res[0][1]:
+        rel = float((res[1][1][n] - res[0][1][n]).norm() / (res[0][1][n].norm() + 1e-12))
+        assert rel <= 5e-3, f"{n}: {rel:.3e}"
 
 
 def test_two_plans_with_different_options_share_a_process():

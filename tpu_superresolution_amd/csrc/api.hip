@@ -360,6 +360,7 @@ const OptEntry kOptions[] = {
     {"wgrad_stream_w8", [] { return srk_wgrad_w8_enabled(); }, [](int v) { srk_wgrad_w8_enable(v); return (int)SRK_OK; }},
     {"block_light", [] { return srk_block_light_enabled(); }, [](int v) { srk_block_light_enable(v); return (int)SRK_OK; }},
     {"mlp_bwd_fused", [] { return srk_mlp_bwd_fused_enabled(); }, [](int v) { srk_mlp_bwd_fused_enable(v); return (int)SRK_OK; }},
+    {"mlp_dgelu_store", [] { return srk_mlp_dgelu_store_enabled(); }, [](int v) { srk_mlp_dgelu_store_enable(v); return (int)SRK_OK; }},
     {"mlp_fused", [] { return srk_mlp_fused_enabled(); }, [](int v) { srk_mlp_fused_enable(v); return (int)SRK_OK; }},
     {"wgrad_stream", [] { return srk_wgrad_stream_enabled(); }, [](int v) { srk_wgrad_stream_enable(v); return (int)SRK_OK; }},
     {"conv_wgrad_taps", [] { return srk_conv_wgrad_taps_mode(); }, [](int v) { srk_conv_wgrad_taps_enable(v); return (int)SRK_OK; }},

@@ -30,7 +30,7 @@ int srk_device_cus();         // multiProcessorCount of the current device (cach
 enum SrkOptId {
   OPT_MLP_FUSED, OPT_MLP_BWD_FUSED, OPT_GEMM_STREAM, OPT_TUNE_BM, OPT_TUNE_KS2, OPT_TUNE_SPLIT, OPT_TUNE_NB, OPT_ATTN_BWD_FUSED,
   OPT_ATTN_FUSED, OPT_BLOCK_LIGHT, OPT_TAPS_ENABLED, OPT_TAPS_DMA, OPT_WGRAD_STREAM, OPT_WGRAD_ROWS, OPT_WGRAD_NT, OPT_WGRAD_W8,
-  OPT_WGRAD_PARTIALS, SRK_NUM_OPTS
+  OPT_WGRAD_PARTIALS, OPT_MLP_DGELU_STORE, SRK_NUM_OPTS
 };
 struct SrkOptTls {
   int v[SRK_NUM_OPTS];
@@ -135,6 +135,20 @@ __device__ __forceinline__ float dgelu_shared_exp(float x) {
   const float e = __expf(-ax * ax);                 // = exp(-x^2 / 2)
   const float erf = copysignf(1.0f - p * t * e, z);
   return fmaf(x * 0.39894228040143268f, e, fmaf(0.5f, erf, 0.5f));
+}
+// gelu(x) (the same operations as gelu_f: bit-identical) and gelu'(x) from one exp and one rcp
+__device__ __forceinline__ void gelu_both(float x, float& gl, float& dg) {
+  const float z = x * 0.70710678118654752f;
+  const float ax = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float erf = copysignf(1.0f - p * t * e, z);
+  gl = 0.5f * x * (1.0f + erf);
+  dg = fmaf(x * 0.39894228040143268f, e, fmaf(0.5f, erf, 0.5f));
 }
 __device__ __forceinline__ uint2 gelu_pack4(float v0, float v1, float v2, float v3) {
   return pack_bf4(gelu_f(v0), gelu_f(v1), gelu_f(v2), gelu_f(v3));

@@ -85,6 +85,8 @@ struct GemmParams {
   const bf16_t* W2;       // fc2 weights [N][HP] bf16
   const float* bias2;     // [N]
   bf16_t* u_out;          // [M][HP] pre-activation (training: read by the backward pass) or null
+  int u_dgelu;            // fused MLP pair only: u_out (forward) / aux (backward) holds gelu'(u) instead of u -- the backward front waves
+                          // then multiply instead of evaluating erf + exp per element (they are VALU-bound on it)
   bf16_t* h_out;          // [M][HP] gelu(u)         (training: operand of the fc2 weight gradient) or null
   int HP;                 // hidden width (padded), 384
 };
@@ -106,5 +108,7 @@ int srk_mlp_fused_enabled();
 // ... and its backward: d u = (d x2 . W2) * gelu'(u) stays in LDS between the two dgrads, the LayerNorm (norm2) backward rides in the
 // second one's epilogue.  A = d x2, Wt = W2^T, aux = u, u_out = d u (output), W2 = W1^T, HP = 384 + the EP_LNBWD fields.
 int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream);
+void srk_mlp_dgelu_store_enable(int on);
+int srk_mlp_dgelu_store_enabled();
 void srk_mlp_bwd_fused_enable(int on);
 int srk_mlp_bwd_fused_enabled();

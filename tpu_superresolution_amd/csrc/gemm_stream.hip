@@ -780,6 +780,7 @@ struct MlpCfg {
   static_assert(C::P * (R - 4) <= 63, "vmcnt overflow");
 };
 
+template <bool DG>        // DG: the u tile carries gelu'(u) for mlp_fused_bwd_kernel<true>
 __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(const GemmParams p, int groups_per_xcd) {
   using M = MlpCfg;
   using C = M::C;
@@ -862,8 +863,15 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(const GemmParams p, 
           const float v0 = acc[j][0] + bv.x, v1 = acc[j][1] + bv.y, v2 = acc[j][2] + bv.z, v3 = acc[j][3] + bv.w;
           const int n = lw * 96 + 16 * j + 4 * g;               // 16-byte chunk n / 8, half (n & 4)
           const int off = r16 * (M::HP * 2) + ((((n >> 3) ^ (r16 & 7)) << 4) | ((n & 4) << 1));
-          *reinterpret_cast<uint2*>(us + off) = pack_bf4(v0, v1, v2, v3);
-          *reinterpret_cast<uint2*>(hs + off) = gelu_pack4(v0, v1, v2, v3);
+          if constexpr (DG) {
+            float g0, g1, g2, g3, d0, d1, d2, d3;
+            gelu_both(v0, g0, d0); gelu_both(v1, g1, d1); gelu_both(v2, g2, d2); gelu_both(v3, g3, d3);
+            *reinterpret_cast<uint2*>(us + off) = pack_bf4(d0, d1, d2, d3);
+            *reinterpret_cast<uint2*>(hs + off) = pack_bf4(g0, g1, g2, g3);
+          } else {
+            *reinterpret_cast<uint2*>(us + off) = pack_bf4(v0, v1, v2, v3);
+            *reinterpret_cast<uint2*>(hs + off) = gelu_pack4(v0, v1, v2, v3);
+          }
         }
       }
       lds_barrier();                                            // B(i): (back-wave hand-over of T2)
@@ -990,6 +998,7 @@ struct MlpBwdCfg {
   static_assert(PF + PB <= 63, "vmcnt overflow");
 };
 
+template <bool DG>        // DG: aux holds gelu'(u) (written by mlp_fused_fwd_kernel<true>)
 __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(const GemmParams p, int groups_per_xcd) {
   using M = MlpBwdCfg;
   using CB = M::CB;
@@ -1089,7 +1098,8 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(const GemmParams p, 
           float u0, u1, u2, u3;
           unpack_bf2(ua.x, u0, u1);
           unpack_bf2(ua.y, u2, u3);
-          *reinterpret_cast<uint2*>(ds + off) = dgelu_mul_pack4(acc[j][0], acc[j][1], acc[j][2], acc[j][3], u0, u1, u2, u3);
+          if constexpr (DG) *reinterpret_cast<uint2*>(ds + off) = pack_bf4(acc[j][0] * u0, acc[j][1] * u1, acc[j][2] * u2, acc[j][3] * u3);
+          else *reinterpret_cast<uint2*>(ds + off) = dgelu_mul_pack4(acc[j][0], acc[j][1], acc[j][2], acc[j][3], u0, u1, u2, u3);
         }
       }
       lds_barrier();                                            // B(i)
@@ -1210,6 +1220,7 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(const GemmParams p, 
 
 SrkOpt g_mlp_fused_enabled{OPT_MLP_FUSED, 1};
 SrkOpt g_mlp_bwd_fused_enabled{OPT_MLP_BWD_FUSED, 1};
+SrkOpt g_mlp_dgelu_store{OPT_MLP_DGELU_STORE, 1};   // fused MLP pair of the training plan: keep gelu'(u) instead of u between the passes
 
 SrkOpt g_stream_enabled{OPT_GEMM_STREAM, -1};     // -1: read SRK_GEMM_STREAM once
 thread_local int g_num_cus = 0;      // CU count of the device the current launch goes to (refreshed by every launcher)
@@ -1392,17 +1403,22 @@ int srk_launch_mlp_fused(const GemmParams& p, hipStream_t stream) {
   if (p.M % 64 != 0 || p.M < 64 * g_num_cus || p.M >= (1 << 24)) return SRK_NOT_COVERED;
   if (p.rowscale && (p.rows_per_sample <= 0 || p.rows_per_sample % 64 != 0)) return SRK_NOT_COVERED;
   if (!p.A || !p.Wt || !p.W2 || !p.res || !p.outf || (p.u_out != nullptr) != (p.h_out != nullptr)) return SRK_NOT_COVERED;
-  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
-  const int rc = stream_configure(&mlp_fused_fwd_kernel, MlpCfg::LDS, &configured);
+  if (p.u_dgelu && !p.u_out) return SRK_NOT_COVERED;
+  static SrkPerDevice<int> configured_pd[2]; int& configured = configured_pd[p.u_dgelu ? 1 : 0].here();
+  const int rc = p.u_dgelu ? stream_configure(&mlp_fused_fwd_kernel<true>, MlpCfg::LDS, &configured)
+                           : stream_configure(&mlp_fused_fwd_kernel<false>, MlpCfg::LDS, &configured);
   if (rc) return rc;
   if (configured < 0) return SRK_NOT_COVERED;       // the build spilled: never run it (scratch traffic would break the counted waits)
   srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
-  hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(g_num_cus), dim3(512), MlpCfg::LDS, stream, p, g_num_cus / 8);
+  if (p.u_dgelu) hipLaunchKernelGGL(mlp_fused_fwd_kernel<true>, dim3(g_num_cus), dim3(512), MlpCfg::LDS, stream, p, g_num_cus / 8);
+  else hipLaunchKernelGGL(mlp_fused_fwd_kernel<false>, dim3(g_num_cus), dim3(512), MlpCfg::LDS, stream, p, g_num_cus / 8);
   srk_probe_post(FAM_GEMM_LINEAR, stream);
   return srk_check_launch("mlp_fused");
 }
 
 void srk_mlp_bwd_fused_enable(int on) { g_mlp_bwd_fused_enabled = on ? 1 : 0; }
+void srk_mlp_dgelu_store_enable(int on) { g_mlp_dgelu_store = on ? 1 : 0; }
+int srk_mlp_dgelu_store_enabled() { return g_mlp_dgelu_store; }
 int srk_mlp_bwd_fused_enabled() { return g_mlp_bwd_fused_enabled; }
 
 // A = d x2 bf16 [M][lda], Wt = W2^T [384][192], aux = u [M][HP], u_out = d u [M][HP] (written), W2 = W1^T [192][384]; the
@@ -1422,12 +1438,14 @@ int srk_launch_mlp_fused_bwd(const GemmParams& p, hipStream_t stream) {
   if (!p.A || !p.Wt || !p.W2 || !p.aux || !p.u_out || !p.outf || !p.ln_x || !p.ln_mean || !p.ln_rstd || !p.ln_gamma || !p.ln_dgamma ||
       !p.ln_dbeta || p.ln_rows_window != 0)
     return SRK_NOT_COVERED;
-  static SrkPerDevice<int> configured_pd; int& configured = configured_pd.here();
-  const int rc = stream_configure(&mlp_fused_bwd_kernel, MlpBwdCfg::LDS, &configured);
+  static SrkPerDevice<int> configured_pd[2]; int& configured = configured_pd[p.u_dgelu ? 1 : 0].here();
+  const int rc = p.u_dgelu ? stream_configure(&mlp_fused_bwd_kernel<true>, MlpBwdCfg::LDS, &configured)
+                           : stream_configure(&mlp_fused_bwd_kernel<false>, MlpBwdCfg::LDS, &configured);
   if (rc) return rc;
   if (configured < 0) return SRK_NOT_COVERED;       // the build spilled: never run it (scratch traffic would break the counted waits)
   srk_probe_pre(FAM_GEMM_LINEAR, stream, p.flops, p.bytes);
-  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(g_num_cus), dim3(512), MlpBwdCfg::LDS, stream, p, g_num_cus / 8);
+  if (p.u_dgelu) hipLaunchKernelGGL(mlp_fused_bwd_kernel<true>, dim3(g_num_cus), dim3(512), MlpBwdCfg::LDS, stream, p, g_num_cus / 8);
+  else hipLaunchKernelGGL(mlp_fused_bwd_kernel<false>, dim3(g_num_cus), dim3(512), MlpBwdCfg::LDS, stream, p, g_num_cus / 8);
   srk_probe_post(FAM_GEMM_LINEAR, stream);
   return srk_check_launch("mlp_fused_bwd");
 }

@@ -57,6 +57,7 @@ struct Workspace {
   int B = 0, H0 = 0, W0 = 0, H = 0, W = 0, training = 0;
   int attn_recompute = 0;      // training: the attention backward re-projects q/k/v (attn_bwd_fused.hip); the forward stores none
   int ckpt = 0;                // training with use_checkpoint: ao / u / h of all blocks share one buffer set, refilled in backward
+  int u_is_dgelu = 0;          // the last forward's fused MLP kernels stored gelu'(u) in the u buffers (GemmParams::u_dgelu)
   size_t ck_x = 0;             // ... scratch for the re-run MLP forward's residual output (discarded)
   int opt_sig = 0;             // option values the layout depends on
   long long T = 0;
@@ -870,10 +871,15 @@ int forward_body(const Ctx& c, int B, const float* drop_scale, bool fuse_final) 
         gf.h_out = (w.training && !w.ckpt) ? c.at<bf16_t>(ba.h) : nullptr;
         gf.flops = 2.0 * fl_mlp;
         gf.bytes = (double)T * (2.0 * C + 4.0 * C + 4.0 * C + 2.0 * C + (w.training ? 4.0 * p->HID : 0.0)) + 4.0 * C * p->HID;   // xn2, x1 in; x2, xb | xn1 (, u, h) out
+        // the only reader of u is the backward's gelu'(u): when the fused backward kernel will run (same shape conditions as the
+        // fused forward), the forward keeps gelu'(u) itself
+        gf.u_dgelu = gf.u_out && fuse_ln && srk_mlp_bwd_fused_enabled() && srk_mlp_dgelu_store_enabled();
         const int rc_mlp = srk_launch_mlp_fused(gf, st);
         if (rc_mlp != SRK_NOT_COVERED) {
           RUN(rc_mlp);
+          p->ws.u_is_dgelu = gf.u_dgelu;
         } else {
+          p->ws.u_is_dgelu = 0;
           RUN(srk_launch_gemm(LD_ROWS, EP_GELU, g1, st));
           RUN(srk_launch_gemm(LD_ROWS, EP_RES, g, st));
         }
@@ -1257,8 +1263,14 @@ int srk_swinir_backward(srk_swinir_plan* plan, const float* params, const void* 
           g.ln_rows_window = 0; g.ln_stats_by_m = 0; g.ln_out_window = 1;
           g.flops = 2.0 * fl_mlp;
           g.bytes = (double)T * (2.0 * C + 2.0 * p->HID + 2.0 * p->HID + 4.0 * C + 8.0 * C + 2.0 * C) + 4.0 * C * p->HID;   // d x2, u in; d u out; x1, gx in; gx, gxbw out
+          g.u_dgelu = w.u_is_dgelu && !w.ckpt;      // use_checkpoint refills u itself (EP_GELU above)
           rc_mlpb = srk_launch_mlp_fused_bwd(g, st);
           if (rc_mlpb != SRK_NOT_COVERED) RUN(rc_mlpb);
+        }
+        if (rc_mlpb == SRK_NOT_COVERED && w.u_is_dgelu && !w.ckpt) {
+          srk_set_error("train step: the forward stored gelu'(u) for the fused MLP backward, which is not available now "
+                        "(mlp_bwd_fused / gemm_stream changed between forward and backward?)");
+          return SRK_E_UNSUPPORTED;
         }
         if (rc_mlpb == SRK_NOT_COVERED) {  // d h = d x2 . Wfc2 ; d u = d h * gelu'(u)
           GemmParams g = {};
