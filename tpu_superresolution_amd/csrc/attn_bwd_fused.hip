@@ -24,8 +24,7 @@
 //   phase C     key tile r of head hl: dV^T, dK^T (8 MFMAs, transposing reads of P, dS, dO, Q)
 // Three barriers per window.  Two 48 KB row slots alternate between the windows: a window's P / dS tiles overwrite ITS OWN xn1 / g
 // rows once the projection has consumed them, so the other slot is free from the window's first barrier on and the rows of the
-// NEXT window are fetched into it by LDS-DMA (four 1-KiB pieces per wave) under the whole window (projection, phases B and C:
-// with the fetch issued behind the projection only, it had 1.3 us to land and every window waited for it).  A wave issues
+// NEXT window are fetched into it by LDS-DMA (four 1-KiB pieces per wave) under phases B and C (SRK_ABF_ISSUE_AT below).  A wave issues
 // exactly three store instructions (dq, dk, dv) between its DMAs and the next window's first barrier, so `s_waitcnt vmcnt(3)`
 // there waits for the DMAs and not for the stores.
 //
@@ -51,6 +50,12 @@ constexpr int OFF_PB = OFF_TAB + 2704;           // [hl][q, k, v][32] fp32 proje
 constexpr int H_LDS = OFF_PB + 10 * 32 * 4;      // 151 440 B
 static_assert(6 * H_PT * 2 == H_PAIR, "P / dS tiles of a head triple fill a row slot exactly");
 
+#ifndef SRK_ABF_ISSUE_AT
+// Where the next window's row DMAs are issued: behind barrier A (0), behind barrier B (1), behind barrier C (2) or inside phase B
+// behind its MFMAs (3).  Measured in the cfg3 step: 95.2 / 91.0 / 112.0 / 91.3 us per launch -- issued into the projection, the four
+// DMA instructions of every wave compete with its ds_read_b128 stream; behind C the rows land too late.
+#define SRK_ABF_ISSUE_AT 1
+#endif
 #ifdef SRK_PROBE_ABF
 // developer instrumentation (never in the shipped build): s_memrealtime (100 MHz) at the phase boundaries of workgroup 0
 __device__ unsigned long long g_abf_probe[12 * 16 * 8];
@@ -191,12 +196,12 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
     for (long long t = 0; t < nwin; ++t) {
       const long long b_ = first + t * stride;
       if (t == 0) srk_wait_vmcnt<0>();                    // table / weight loads and the first DMAs
-      else srk_wait_vmcnt<3>();                           // everything but this wave's dq / dk / dv stores of window t-1
+      else srk_wait_vmcnt<SRK_ABF_ISSUE_AT == 2 ? 2 : 3>();   // everything but this wave's dq / dk / dv stores of window t-1 behind the DMAs
       ABF_MARK(0);
       srk_lds_barrier();                                  // A: the rows of window t are in LDS; nobody reads window t-1's tiles
       ABF_MARK(1);
       const int cur = (int)(t & 1);
-      if (t + 1 < nwin) issue(b_ + stride, cur ^ 1);      // the other slot held P / dS of window t-1: dead since this barrier
+      if (SRK_ABF_ISSUE_AT == 0 && t + 1 < nwin) issue(b_ + stride, cur ^ 1);      // the other slot held P / dS of window t-1: dead since this barrier
       const unsigned char* src = smem + OFF_S + cur * H_PAIR + (it < 3 ? 0 : H_SLOT);
       bf16_t* Pb = reinterpret_cast<bf16_t*>(smem + OFF_S + cur * H_PAIR) + (hl * 2 + 0) * H_PT;
       bf16_t* Db = Pb + H_PT;
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
       ABF_MARK(2);
       srk_lds_barrier();                                  // B: the twelve tiles are complete; this window's rows are consumed
       ABF_MARK(3);
+      if (SRK_ABF_ISSUE_AT == 1 && t + 1 < nwin) issue(b_ + stride, cur ^ 1);
 
       // ---- phase B: query tile `it` of head hl against all 64 keys ---------------------------------------------------------------
       {
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
 #pragma unroll
           for (int jt = 0; jt < 2; ++jt) dp[jt + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], of, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
+        if (SRK_ABF_ISSUE_AT == 3 && t + 1 < nwin) issue(b_ + stride, cur ^ 1);   // behind the unit's MFMAs, in front of the softmax VALU work
         const int w = (int)((unsigned)b_ % (unsigned)p.geom.nW);      // 32-bit: the launcher bounds B_
         const int wy = w / p.geom.nWw, wx = w - wy * p.geom.nWw;
         const bool masked = p.geom.shift > 0 && (wy == p.geom.H / 8 - 1 || wx == p.geom.nWw - 1);
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(768) void qkv_attn_bwd_kernel(const BwdFusedParams 
       ABF_MARK(4);
       srk_lds_barrier();                                  // C: P and dS of the three heads are complete
       ABF_MARK(5);
+      if (SRK_ABF_ISSUE_AT == 2 && t + 1 < nwin) issue(b_ + stride, cur ^ 1);
 
       // ---- phase C: key tile jt = `it` of head hl: dV^T, dK^T summed over all 64 queries ----------------------------------------------
       {
