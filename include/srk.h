@@ -457,6 +457,31 @@ int srk_chan_gram(const uint16_t* x, int ldx, const uint16_t* y, int ldy, float*
 int srk_chan_apply_mat(const float* M, const uint16_t* src, int ldsrc, const float* diag, const uint16_t* src2, int ldsrc2, uint16_t* out, int ldo,
                        int B, int N, int num_heads, int accumulate, srk_stream_t stream);
 
+/* DAT training, the small functions between token passes as one launch each (csrc/dat_small.hip):
+ *   srk_channel_interaction_fwd / _bwd: channel_interaction (dat_arch.py:315-321) on the pooled 1 x 1 map: pooled [B][ldp] = per-sample token
+ *     sums in the head-padded channel order, pad_of[c] = padded position of real channel c; pm = pooled[pad_of] * inv_hw -> 1x1 conv W1 [S][C]
+ *     -> BatchNorm2d over the BATCH (batch statistics; running buffers, if given, move as nn.BatchNorm2d's do) -> GELU -> 1x1 conv W2 [C][S]
+ *     -> sigmoid -> cgate [B][CA] (padding 0); pm_out [B][C] is what the backward needs.  _bwd: d cgate [B][ldg] (head-padded) -> the six
+ *     parameter gradients and dpool [B][CA] = d pm * inv_hw scattered back (padding 0).  Limits: B > 1, S <= 64, B*C <= 6144, B*S <= 768
+ *     (SRK_E_SHAPE beyond: the caller keeps a torch path for larger batches).
+ *   srk_chan_attn_matrix_fwd / _bwd: Adaptive_Channel_Attention's d x d matrix (:497-503) from the chunk partials of srk_chan_gram(q, k):
+ *     gram [B][heads][1088] = their sum (G | sum q^2 | sum k^2), A [B][heads][32][32] = softmax_j(temperature_h G_ij / (|q_i| |k_j|)) over the
+ *     dh real channels (norms clamped at 1e-12 as F.normalize; padding rows / columns 0).  _bwd: dpartial = chunk partials of
+ *     srk_chan_gram(d out, v) (= d A) -> dG, dGt (its transpose), dsq2 / dsk2 [B][heads][32] (the diagonal coefficients of d q / d k through
+ *     the norms, as srk_chan_apply_mat takes them), dtemp [B][heads] (sum over B = d temperature). */
+int srk_channel_interaction_fwd(const float* pooled, int ldp, float inv_hw, const int* pad_of, const float* W1, const float* b1,
+                                const float* gamma, const float* beta, float eps, const float* W2, const float* b2, float* running_mean,
+                                float* running_var, float momentum, float* pm_out, float* cgate, int B, int C, int S, int CA,
+                                srk_stream_t stream);
+int srk_channel_interaction_bwd(const float* pm, const float* dcgate, int ldg, float inv_hw, const int* pad_of, const float* W1,
+                                const float* b1, const float* gamma, const float* beta, float eps, const float* W2, const float* b2,
+                                float* dW1, float* db1, float* dgamma, float* dbeta, float* dW2, float* db2, float* dpool, int B, int C, int S,
+                                int CA, srk_stream_t stream);
+int srk_chan_attn_matrix_fwd(const float* partial, int nchunk, const float* temperature, float* gram, float* A, int B, int num_heads, int dh,
+                             srk_stream_t stream);
+int srk_chan_attn_matrix_bwd(const float* dpartial, int nchunk, const float* gram, const float* A, const float* temperature, float* dG, float* dGt,
+                             float* dsq2, float* dsk2, float* dtemp, int B, int num_heads, int dh, srk_stream_t stream);
+
 /* ---- whole-model executor: SwinIR.forward / backward  (network_swinir.py:805-840) ------------------- */
 enum { SRK_UPSAMPLER_PIXELSHUFFLE = 1,          /* classical SR           (network_swinir.py:740-745, :813-817) */
        SRK_UPSAMPLER_PIXELSHUFFLEDIRECT = 2,    /* lightweight SR         (:746-749, :818-822) */

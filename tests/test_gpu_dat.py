@@ -359,7 +359,14 @@ def test_dat_channel_attention_train_path_vs_autograd():
     check(L.srk_chan_gram(qd.data_ptr(), 3 * CA, qd.data_ptr() + CA * 2, 3 * CA, part.data_ptr(), B, N, nH, _st()))
     gg = part.view(B, nH, -1, 1088).sum(2)
     G, sq, sk = gg[..., :1024].reshape(B, nH, 32, 32), gg[..., 1024:1056], gg[..., 1056:]
-    A = DT._channel_attention_matrix(G, sq, sk, temp.cuda(), dh).contiguous()
+    A_t = DT._channel_attention_matrix(G, sq, sk, temp.cuda(), dh).contiguous()
+    # the one-launch form of the same function (csrc/dat_small.hip): chunk partials -> gram, A
+    tempd = temp.cuda().contiguous()
+    nchunk = part.numel() // (B * nH * 1088)
+    gram, A = torch.empty(B, nH, 1088, device="cuda"), torch.full((B, nH, 32, 32), 7.0, device="cuda")
+    check(L.srk_chan_attn_matrix_fwd(part.data_ptr(), nchunk, tempd.data_ptr(), gram.data_ptr(), A.data_ptr(), B, nH, dh, _st()))
+    assert _rel(gram.cpu(), gg.cpu()) <= 1e-6
+    assert float((A - A_t).abs().max()) <= 1e-6
     assert float((A[..., :dh, :dh].cpu() - attn.detach()).abs().max()) <= 1e-5
     att = torch.zeros(B * N, CA, dtype=torch.bfloat16, device="cuda")
     check(L.srk_chan_apply_mat(A.data_ptr(), qd.data_ptr() + 2 * CA * 2, 3 * CA, None, None, 0, att.data_ptr(), CA, B, N, nH, 0, _st()))
@@ -373,7 +380,15 @@ def test_dat_channel_attention_train_path_vs_autograd():
     check(L.srk_chan_apply_mat(At.data_ptr(), dod.data_ptr(), CA, None, None, 0, dqkv.data_ptr() + 2 * CA * 2, 3 * CA, B, N, nH, 0, _st()))
     Gm, sqm, skm, tm = (t.detach().requires_grad_(True) for t in (G, sq, sk, temp.cuda()))
     dG, dsq, dsk, dtemp = torch.autograd.grad(DT._channel_attention_matrix(Gm, sqm, skm, tm, dh), [Gm, sqm, skm, tm], dA)
-    dG, dGt, dsq2, dsk2 = dG.contiguous(), dG.transpose(-1, -2).contiguous(), (2 * dsq).contiguous(), (2 * dsk).contiguous()
+    dG_t, dsq2_t, dsk2_t = dG.contiguous(), (2 * dsq).contiguous(), (2 * dsk).contiguous()
+    dG, dGt = torch.full((B, nH, 32, 32), 7.0, device="cuda"), torch.full((B, nH, 32, 32), 7.0, device="cuda")
+    dsq2, dsk2, dtemp_bh = torch.full((B, nH, 32), 7.0, device="cuda"), torch.full((B, nH, 32), 7.0, device="cuda"), torch.empty(B, nH, device="cuda")
+    check(L.srk_chan_attn_matrix_bwd(part.data_ptr(), nchunk, gram.data_ptr(), A.data_ptr(), tempd.data_ptr(), dG.data_ptr(), dGt.data_ptr(),
+                                     dsq2.data_ptr(), dsk2.data_ptr(), dtemp_bh.data_ptr(), B, nH, dh, _st()))
+    assert _rel(dG.cpu(), dG_t.cpu()) <= 1e-4 and torch.equal(dGt, dG.transpose(-1, -2))
+    assert _rel(dsq2.cpu(), dsq2_t.cpu()) <= 1e-4 and _rel(dsk2.cpu(), dsk2_t.cpu()) <= 1e-4
+    assert _rel(dtemp_bh.sum(0).cpu(), dtemp.flatten().cpu()) <= 1e-4
+    dtemp = dtemp_bh.sum(0).view(nH, 1, 1)
     check(L.srk_chan_apply_mat(dG.data_ptr(), qd.data_ptr() + CA * 2, 3 * CA, dsq2.data_ptr(), qd.data_ptr(), 3 * CA, dqkv.data_ptr(), 3 * CA, B, N, nH, 0,
                                _st()))
     check(L.srk_chan_apply_mat(dGt.data_ptr(), qd.data_ptr(), 3 * CA, dsk2.data_ptr(), qd.data_ptr() + CA * 2, 3 * CA, dqkv.data_ptr() + CA * 2, 3 * CA, B,
@@ -382,6 +397,68 @@ def test_dat_channel_attention_train_path_vs_autograd():
     for w_, nm in enumerate("qkv"):
         assert _rel(got[w_], r.grad[w_]) <= 2e-2, nm
     assert _rel(dtemp.cpu(), tr.grad) <= 1e-3
+
+
+@pytest.mark.parametrize("B,C,S,nH", [(16, 180, 22, 6), (3, 60, 7, 4), (5, 24, 3, 2)])
+def test_dat_channel_interaction_kernels_vs_autograd(B, C, S, nH):
+    """srk_channel_interaction_fwd / _bwd (csrc/dat_small.hip) against dat_train._channel_interaction under autograd (the formulation of
+    dat_arch.py:315-321 on a 1 x 1 map with BatchNorm batch statistics): gate, running buffers, all six parameter gradients and the
+    pooled gradient, through the head-padded channel layout."""
+    from tpu_superresolution_amd import dat_train as DT
+    from tpu_superresolution_amd import hat_arch as ha
+    check, L = _lib()
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    dh = C // nH
+    CA, HW = nH * 32, 64
+    ci = torch.nn.Sequential(torch.nn.AdaptiveAvgPool2d(1), torch.nn.Conv2d(C, S, 1), torch.nn.BatchNorm2d(S), torch.nn.GELU(),
+                             torch.nn.Conv2d(S, C, 1)).cuda()
+    with torch.no_grad():
+        for p_ in ci.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.5)
+        ci[2].running_mean.copy_(torch.randn(S, generator=g))
+        ci[2].running_var.copy_(torch.rand(S, generator=g) + 0.5)
+    rm0, rv0 = ci[2].running_mean.clone(), ci[2].running_var.clone()
+    hm = ha._head_map(nH, dh, torch.device("cuda"))
+    pooled = torch.zeros(B, 2, CA, device="cuda")
+    pooled[:, 0, hm] = (torch.randn(B, C, generator=g) * HW).cuda()
+    pooled[:, 1] = 99.0                                                   # the second row of the partial sums is not read
+    dcg = torch.zeros(B, CA, device="cuda")
+    dcg[:, hm] = torch.randn(B, C, generator=g).cuda()
+    # torch path
+    pm_t = (pooled[:, 0] / HW)[:, hm].contiguous().requires_grad_(True)
+    st_: dict = {}
+    cg_t = DT._channel_interaction(pm_t, ci, st_)
+    params = [ci[1].weight, ci[1].bias, ci[2].weight, ci[2].bias, ci[4].weight, ci[4].bias]
+    grads = torch.autograd.grad(cg_t, [pm_t] + params, dcg[:, hm])
+    DT._bn_update(ci[2], st_["mean"], st_["var"], st_["n"])
+    rm_t, rv_t = ci[2].running_mean.clone(), ci[2].running_var.clone()
+    ci[2].running_mean.copy_(rm0); ci[2].running_var.copy_(rv0)
+    # kernels
+    assert DT._ci_fused_ok(B, C, S, ci)
+    hm32 = hm.to(torch.int32)
+    pm, cgate = torch.empty(B, C, device="cuda"), torch.full((B, CA), 7.0, device="cuda")
+    view = pooled[:, 0]
+    check(L.srk_channel_interaction_fwd(view.data_ptr(), view.stride(0), 1.0 / HW, hm32.data_ptr(), ci[1].weight.data_ptr(), ci[1].bias.data_ptr(),
+                                        ci[2].weight.data_ptr(), ci[2].bias.data_ptr(), float(ci[2].eps), ci[4].weight.data_ptr(), ci[4].bias.data_ptr(),
+                                        ci[2].running_mean.data_ptr(), ci[2].running_var.data_ptr(), float(ci[2].momentum), pm.data_ptr(),
+                                        cgate.data_ptr(), B, C, S, CA, _st()))
+    assert _rel(pm.cpu(), pm_t.detach().cpu()) <= 1e-6
+    assert float((cgate[:, hm] - cg_t.detach()).abs().max()) <= 2e-5
+    pad = torch.ones(CA, dtype=torch.bool, device="cuda"); pad[hm] = False
+    assert float(cgate[:, pad].abs().max()) == 0.0
+    assert _rel(ci[2].running_mean.cpu(), rm_t.cpu()) <= 1e-5 and _rel(ci[2].running_var.cpu(), rv_t.cpu()) <= 1e-5
+    gk = [torch.full(p_.shape, 7.0, device="cuda") for p_ in params]
+    dpool = torch.full((B, CA), 7.0, device="cuda")
+    check(L.srk_channel_interaction_bwd(pm.data_ptr(), dcg.data_ptr(), CA, 1.0 / HW, hm32.data_ptr(), ci[1].weight.data_ptr(), ci[1].bias.data_ptr(),
+                                        ci[2].weight.data_ptr(), ci[2].bias.data_ptr(), float(ci[2].eps), ci[4].weight.data_ptr(), ci[4].bias.data_ptr(),
+                                        gk[0].data_ptr(), gk[1].data_ptr(), gk[2].data_ptr(), gk[3].data_ptr(), gk[4].data_ptr(), gk[5].data_ptr(),
+                                        dpool.data_ptr(), B, C, S, CA, _st()))
+    for nm, got, want in zip(("W1", "b1", "gamma", "beta", "W2", "b2"), gk, grads[1:]):
+        if nm == "b1":                   # a bias in front of a BatchNorm: exactly zero in exact arithmetic, rounding noise in both
+            assert float(got.abs().max()) <= 1e-4 * max(1.0, float(grads[1].abs().max())), nm
+        else:
+            assert _rel(got.cpu(), want.cpu()) <= 2e-4, nm
+    assert _rel(dpool[:, hm].cpu(), (grads[0] / HW).cpu()) <= 2e-4 and float(dpool[:, pad].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("wh,ww,shift,H,W", [(8, 32, True, 32, 64), (32, 8, False, 24, 40), (8, 16, True, 24, 40), (16, 8, True, 32, 32)])

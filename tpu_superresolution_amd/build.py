@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsrk.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_stream.hip", "wgrad.hip", "convwgrad.hip", "attn.hip", "attn_fused.hip", "attn_bwd_fused.hip", "block_light.hip", "ln.hip", "misc.hip", "swinir.hip", "attn256.hip", "hat.hip", "hat_train.hip", "attn256_bwd.hip", "metrics.hip", "dat.hip", "dat_train.hip", "attn_rect_bwd.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_stream.hip", "wgrad.hip", "convwgrad.hip", "attn.hip", "attn_fused.hip", "attn_bwd_fused.hip", "block_light.hip", "ln.hip", "misc.hip", "swinir.hip", "attn256.hip", "hat.hip", "hat_train.hip", "attn256_bwd.hip", "metrics.hip", "dat.hip", "dat_train.hip", "attn_rect_bwd.hip", "dat_small.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result",
          "-Wno-subobject-linkage"]
 FLAGS += os.environ.get("SRK_EXTRA_FLAGS", "").split()   # developer experiments (-DSRK_NT_GEMM=1 ...); touch the source to rebuild

@@ -116,6 +116,19 @@ def _channel_interaction(pm: torch.Tensor, ci: nn.Sequential, stats: Optional[di
     return torch.sigmoid(F.linear(F.gelu(y), ci[4].weight.flatten(1), ci[4].bias))
 
 
+def _ci_fused_ok(B: int, C: int, S: int, ci: nn.Sequential) -> bool:
+    """srk_channel_interaction_fwd / _bwd cover this shape (csrc/dat_small.hip limits) and the BatchNorm has a fixed momentum"""
+    bn = ci[2]
+    return (B > 1 and S <= 64 and B * C <= 6144 and B * S <= 768 and bn.affine and ci[1].weight.dtype == torch.float32
+            and (not bn.track_running_stats or bn.running_mean is None or (bn.momentum is not None and bn.running_mean.dtype == torch.float32)))
+
+
+def _hm32(hm: torch.Tensor) -> torch.Tensor:
+    """int32 copy of a head map (padded position of every real channel), cached per map"""
+    from . import hat_arch
+    return hat_arch._cached_map(("hm32", hm.data_ptr(), hm.numel()), lambda: hm.to(torch.int32))
+
+
 def _channel_attention_matrix(G: torch.Tensor, sq: torch.Tensor, sk: torch.Tensor, temp: torch.Tensor, dh: int) -> torch.Tensor:
     """G [B][h][32][32] = q^T k, sq / sk = column norms^2 of q / k -> softmax((q / |q|)^T (k / |k|) * temperature) over the dh real
     key channels, rows and columns of the padding zero (dat_arch.py:497-503; F.normalize clamps the norm at 1e-12)"""
@@ -340,20 +353,35 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
             else:
                 part = torch.empty(int(L.srk_chan_gram_floats(B, HW, nH)), **f32)
                 check(L.srk_chan_gram(qkv.data_ptr(), 3 * CA, qkv.data_ptr() + CA * 2, 3 * CA, part.data_ptr(), B, HW, nH, st))
-                g = part.view(B, nH, -1, 1088).sum(2)
-                G, sq, sk = g[..., :1024].reshape(B, nH, 32, 32), g[..., 1024:1056], g[..., 1056:]
-                A = _channel_attention_matrix(G, sq, sk, at.temperature.float(), dh).contiguous()
+                gram, A = torch.empty(B, nH, 1088, **f32), torch.empty(B, nH, 32, 32, **f32)      # G | sum q^2 | sum k^2 ; softmax(...)
+                temp = at.temperature.float().contiguous()
+                check(L.srk_chan_attn_matrix_fwd(part.data_ptr(), part.numel() // (B * nH * 1088), temp.data_ptr(), gram.data_ptr(), A.data_ptr(), B,
+                                                 nH, dh, st))
                 check(L.srk_chan_apply_mat(A.data_ptr(), v_ptr, 3 * CA, None, None, 0, att.data_ptr(), CA, B, HW, nH, 0, st))
-                bk.update(G=G, sq=sq, sk=sk, A=A)
+                bk.update(gram=gram, A=A)
                 gate_src, tok_src = att, conv            # channel map from the attention, spatial map from the conv branch
             # channel interaction on the pooled map (:315-321): [B][C] -> sigmoid gate
             pooled, _ = token_sums(gate_src.data_ptr(), CA, gate_src.data_ptr(), CA, CA // 8, per_sample=True)
-            pm = (pooled / HW)[:, hm].contiguous()
-            cst: dict = {}
-            cg = _channel_interaction(pm, at.channel_interaction, cst)
-            _bn_update(at.channel_interaction[2], cst["mean"], cst["var"], cst["n"])
-            cgate = torch.zeros(B, CA, **f32)
-            cgate[:, hm] = cg
+            ci = at.channel_interaction
+            S1 = ci[1].weight.shape[0]
+            if _ci_fused_ok(B, C_, S1, ci):
+                pm, cgate = torch.empty(B, C_, **f32), torch.empty(B, CA, **f32)
+                bnc = ci[2]
+                track = bnc.track_running_stats and bnc.running_mean is not None
+                check(L.srk_channel_interaction_fwd(pooled.data_ptr(), pooled.stride(0), 1.0 / HW, _hm32(hm).data_ptr(), ci[1].weight.data_ptr(), ci[1].bias.data_ptr(),
+                                                    bnc.weight.data_ptr(), bnc.bias.data_ptr(), float(bnc.eps), ci[4].weight.data_ptr(),
+                                                    ci[4].bias.data_ptr(), bnc.running_mean.data_ptr() if track else None,
+                                                    bnc.running_var.data_ptr() if track else None, float(bnc.momentum) if track else 0.0,
+                                                    pm.data_ptr(), cgate.data_ptr(), B, C_, S1, CA, st))
+                if track:
+                    bnc.num_batches_tracked += 1
+            else:
+                pm = (pooled / HW)[:, hm].contiguous()
+                cst: dict = {}
+                cg = _channel_interaction(pm, ci, cst)
+                _bn_update(ci[2], cst["mean"], cst["var"], cst["n"])
+                cgate = torch.zeros(B, CA, **f32)
+                cgate[:, hm] = cg
             # spatial interaction (:322-327): 1x1 conv -> BatchNorm (batch statistics) -> GELU -> 1x1 conv -> sigmoid gate per token
             si = at.spatial_interaction
             S2 = si[0].weight.shape[0]
@@ -629,14 +657,27 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             # channel interaction: autograd on the [B][C] function, then the pooled gradient broadcast back over the tokens
             ci = at.channel_interaction
             ci_params = [ci[1].weight, ci[1].bias, ci[2].weight, ci[2].bias, ci[4].weight, ci[4].bias]
-            with torch.enable_grad():
-                pm = bk["pm"].detach().requires_grad_(True)
-                cg = _channel_interaction(pm, ci)
-                grads = torch.autograd.grad(cg, [pm] + ci_params, dcg_part.sum(1)[:, hm])
-            for p_, g_ in zip(ci_params, grads[1:]):
-                put(p_, g_)
-            dpool = torch.zeros(B, CA, **f32)
-            dpool[:, hm] = grads[0] / HW
+            S1 = ci[1].weight.shape[0]
+            if _ci_fused_ok(B, C_, S1, ci):
+                dcg = dcg_part.sum(1)                                                   # [B][CA], head-padded
+                gci = [torch.empty(p_.shape, **f32) for p_ in ci_params]
+                dpool = torch.empty(B, CA, **f32)
+                check(L.srk_channel_interaction_bwd(bk["pm"].data_ptr(), dcg.data_ptr(), CA, 1.0 / HW, _hm32(hm).data_ptr(), ci[1].weight.data_ptr(),
+                                                    ci[1].bias.data_ptr(), ci[2].weight.data_ptr(), ci[2].bias.data_ptr(), float(ci[2].eps),
+                                                    ci[4].weight.data_ptr(), ci[4].bias.data_ptr(), gci[0].data_ptr(), gci[1].data_ptr(),
+                                                    gci[2].data_ptr(), gci[3].data_ptr(), gci[4].data_ptr(), gci[5].data_ptr(), dpool.data_ptr(), B, C_,
+                                                    S1, CA, st))
+                for p_, g_ in zip(ci_params, gci):
+                    G[pname(p_)] = g_
+            else:
+                with torch.enable_grad():
+                    pm = bk["pm"].detach().requires_grad_(True)
+                    cg = _channel_interaction(pm, ci)
+                    grads = torch.autograd.grad(cg, [pm] + ci_params, dcg_part.sum(1)[:, hm])
+                for p_, g_ in zip(ci_params, grads[1:]):
+                    put(p_, g_)
+                dpool = torch.zeros(B, CA, **f32)
+                dpool[:, hm] = grads[0] / HW
             check(L.srk_lincomb2_bf16(None, 0, None, 0, None, None, dpool.data_ptr(), d_gate_src.data_ptr(), CA, T, CA // 8, HW, 1, st))
             # spatial interaction backward (closed-form BatchNorm backward between two token passes)
             si = at.spatial_interaction
@@ -705,16 +746,16 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             else:
                 part = torch.empty(int(L.srk_chan_gram_floats(B, HW, nH)), **f32)
                 check(L.srk_chan_gram(d_att.data_ptr(), CA, v_ptr, 3 * CA, part.data_ptr(), B, HW, nH, st))
-                dA = part.view(B, nH, -1, 1088).sum(2)[..., :1024].reshape(B, nH, 32, 32)
                 At = bk["A"].transpose(-1, -2).contiguous()
                 check(L.srk_chan_apply_mat(At.data_ptr(), d_att.data_ptr(), CA, None, None, 0, dqkv.data_ptr() + 2 * CA * 2, 3 * CA, B, HW, nH, 0, st))
-                with torch.enable_grad():
-                    Gm, sq, sk = (bk[k].detach().requires_grad_(True) for k in ("G", "sq", "sk"))
-                    A = _channel_attention_matrix(Gm, sq, sk, at.temperature.float(), dh)
-                    dG, dsq, dsk, dtemp = torch.autograd.grad(A, [Gm, sq, sk, at.temperature], dA)
-                put(at.temperature, dtemp)
+                dG, dGt = torch.empty(B, nH, 32, 32, **f32), torch.empty(B, nH, 32, 32, **f32)
+                dsq2, dsk2, dtemp = torch.empty(B, nH, 32, **f32), torch.empty(B, nH, 32, **f32), torch.empty(B, nH, **f32)
+                temp = at.temperature.float().contiguous()
+                check(L.srk_chan_attn_matrix_bwd(part.data_ptr(), part.numel() // (B * nH * 1088), bk["gram"].data_ptr(), bk["A"].data_ptr(),
+                                                 temp.data_ptr(), dG.data_ptr(), dGt.data_ptr(), dsq2.data_ptr(), dsk2.data_ptr(), dtemp.data_ptr(), B, nH,
+                                                 dh, st))
+                put(at.temperature, dtemp.sum(0))
                 q_ptr, k_ptr = qkv.data_ptr(), qkv.data_ptr() + CA * 2
-                dG, dGt, dsq2, dsk2 = dG.contiguous(), dG.transpose(-1, -2).contiguous(), (2.0 * dsq).contiguous(), (2.0 * dsk).contiguous()
                 check(L.srk_chan_apply_mat(dG.data_ptr(), k_ptr, 3 * CA, dsq2.data_ptr(), q_ptr, 3 * CA, dqkv.data_ptr(), 3 * CA, B, HW, nH, 0, st))
                 check(L.srk_chan_apply_mat(dGt.data_ptr(), q_ptr, 3 * CA, dsk2.data_ptr(), k_ptr, 3 * CA, dqkv.data_ptr() + CA * 2, 3 * CA, B, HW, nH, 0, st))
             check(L.srk_lincomb2_bf16(dv_conv.data_ptr(), CA, None, 0, None, None, None, dqkv.data_ptr() + 2 * CA * 2, 3 * CA, T, CA // 8, 0, 1, st))
