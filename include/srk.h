@@ -462,13 +462,15 @@ int srk_chan_apply_mat(const float* M, const uint16_t* src, int ldsrc, const flo
  *     sums in the head-padded channel order, pad_of[c] = padded position of real channel c; pm = pooled[pad_of] * inv_hw -> 1x1 conv W1 [S][C]
  *     -> BatchNorm2d over the BATCH (batch statistics; running buffers, if given, move as nn.BatchNorm2d's do) -> GELU -> 1x1 conv W2 [C][S]
  *     -> sigmoid -> cgate [B][CA] (padding 0); pm_out [B][C] is what the backward needs.  _bwd: d cgate [B][ldg] (head-padded) -> the six
- *     parameter gradients and dpool [B][CA] = d pm * inv_hw scattered back (padding 0).  Limits: B > 1, S <= 64, B*C <= 6144, B*S <= 768
- *     (SRK_E_SHAPE beyond: the caller keeps a torch path for larger batches).
+ *     parameter gradients and dpool [B][CA] = d pm * inv_hw scattered back (padding 0).  One workgroup with both weight matrices and every
+ *     [B][C] / [B][S] array in LDS: srk_channel_interaction_covered(B, C, S) says whether a shape fits (B > 1, S <= 64, 150 KB); SRK_E_SHAPE
+ *     beyond (the caller keeps a torch path for larger batches).
  *   srk_chan_attn_matrix_fwd / _bwd: Adaptive_Channel_Attention's d x d matrix (:497-503) from the chunk partials of srk_chan_gram(q, k):
  *     gram [B][heads][1088] = their sum (G | sum q^2 | sum k^2), A [B][heads][32][32] = softmax_j(temperature_h G_ij / (|q_i| |k_j|)) over the
  *     dh real channels (norms clamped at 1e-12 as F.normalize; padding rows / columns 0).  _bwd: dpartial = chunk partials of
  *     srk_chan_gram(d out, v) (= d A) -> dG, dGt (its transpose), dsq2 / dsk2 [B][heads][32] (the diagonal coefficients of d q / d k through
  *     the norms, as srk_chan_apply_mat takes them), dtemp [B][heads] (sum over B = d temperature). */
+int srk_channel_interaction_covered(int B, int C, int S);
 int srk_channel_interaction_fwd(const float* pooled, int ldp, float inv_hw, const int* pad_of, const float* W1, const float* b1,
                                 const float* gamma, const float* beta, float eps, const float* W2, const float* b2, float* running_mean,
                                 float* running_var, float momentum, float* pm_out, float* cgate, int B, int C, int S, int CA,

@@ -209,3 +209,33 @@ def test_batched_weight_packing_equals_one_tensor_at_a_time():
 
     assert both(hat_p) == 93 and both(hat_pt) == 37 and both(dat_p(False)) == 131 and both(dat_p(True)) == 73 and both(dat_pt) == 58
     assert both(w16_p) == 45
+
+
+def test_zero_arena_serves_the_second_pass_from_one_buffer():
+    """ops.ZeroArena: the first pass learns the size (torch.zeros fallbacks), the following passes carve every request out of one zeroed
+    buffer (256-byte aligned pieces, independent of each other), a larger pass than learnt falls back for the excess, and outside an
+    arena_scope zeros_f32 is plain torch.zeros."""
+    import torch
+    from tpu_superresolution_amd import ops
+    dev = torch.device("cpu")
+    ar = ops.ZeroArena()
+    shapes = [(3, 5), (7,), (2, 2, 9), (64,)]
+    with ops.arena_scope(ar, dev):
+        first = [ops.zeros_f32(s, dev) for s in shapes]
+    assert all(t.shape == torch.Size(s) and float(t.abs().sum()) == 0.0 for t, s in zip(first, shapes))
+    assert ar.need == 4 * 64 and ar.buf is None
+    with ops.arena_scope(ar, dev):
+        second = [ops.zeros_f32(s, dev) for s in shapes]
+        extra = ops.zeros_f32((100,), dev)                      # beyond what the first pass asked for
+    base = ar.buf.data_ptr()
+    assert [t.data_ptr() - base for t in second] == [0, 256, 512, 768]
+    assert not (base <= extra.data_ptr() < base + ar.buf.numel() * 4)
+    second[0].fill_(1.0)
+    assert float(second[1].abs().sum()) == 0.0 and float(ar.buf[15:64].abs().sum()) == 0.0
+    assert ar.need == 4 * 64 + 128
+    kept = second[2]
+    with ops.arena_scope(ar, dev):
+        third = ops.zeros_f32((3, 5), dev)
+    assert third.data_ptr() != second[0].data_ptr() or float(third.abs().sum()) == 0.0     # a fresh buffer per pass: `kept` is untouched
+    assert float(kept.abs().sum()) == 0.0 and float(third.abs().sum()) == 0.0
+    assert ops.zeros_f32((4,), dev).shape == (4,)

@@ -143,6 +143,7 @@ _SIGNATURES = {
     "srk_win_attention_bwd_padded_scratch": (_sz, [_i, _i, _i, _i, _i, _i]),
     "srk_win_attention_bwd_padded": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "srk_bn_train_coeffs": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp]),
+    "srk_channel_interaction_covered": (_i, [_i, _i, _i]),
     "srk_channel_interaction_fwd": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srk_channel_interaction_bwd": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srk_chan_attn_matrix_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -50,13 +50,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict
   }
   __syncthreads();
   const int cg = threadIdx.x;
-  float wr[9][4], sc[4], sh[4];
+  // two channels per VALU lane-operation (v_pk_fma_f32): the 36 multiply-adds per pixel are the kernel's largest instruction block
+  srk_f32x2_t wr[9][2], sc[2], sh[2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t][e] = wsh[(cg * 4 + e) * 11 + t];
-    sc[e] = wsh[(cg * 4 + e) * 11 + 9];
-    sh[e] = wsh[(cg * 4 + e) * 11 + 10];
+    for (int t = 0; t < 9; ++t) wr[t][h] = srk_f32x2_t{wsh[(cg * 4 + 2 * h) * 11 + t], wsh[(cg * 4 + 2 * h + 1) * 11 + t]};
+    sc[h] = srk_f32x2_t{wsh[(cg * 4 + 2 * h) * 11 + 9], wsh[(cg * 4 + 2 * h + 1) * 11 + 9]};
+    sh[h] = srk_f32x2_t{wsh[(cg * 4 + 2 * h) * 11 + 10], wsh[(cg * 4 + 2 * h + 1) * 11 + 10]};
   }
   const long long npix = (long long)B * H * W;
   const long long p0 = ((long long)blockIdx.x * blockDim.y + threadIdx.y) * DW_ITER;
@@ -66,7 +67,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict
   const int x0 = (int)(p0 % W);
   const int y = (int)((p0 / W) % H);
   // every load of the segment is issued before the first use: (DW_ITER + 2) columns x 3 rows of 8 bytes (+ the gating operand) stay
-  // packed in registers; a load placed next to its use paid one memory round trip per pixel (2-3 us each, 87 us per launch)
+  // packed in registers; a load placed next to its use paid one memory round trip per pixel (2-3 us each, 87 us per launch).
+  // Addresses: one 32-bit byte offset per lane (the launcher bounds the tensor by 4 GB) + a wave-uniform offset per (row, column) --
+  // as 64-bit per-load arithmetic the address computation was a quarter of the kernel's instructions.
+  const unsigned lane_off = (unsigned)((p0 * ldx + cg * 4) * 2);
+  const char* xb = reinterpret_cast<const char*>(x);
   uint2 raw[DW_ITER + 2][3], mraw[DW_ITER];
 #pragma unroll
   for (int c = 0; c < DW_ITER + 2; ++c) {
@@ -75,41 +80,56 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict
     for (int r = 0; r < 3; ++r) {
       const int yy = y + r - 1;
       raw[c][r] = make_uint2(0u, 0u);
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-        raw[c][r] = *reinterpret_cast<const uint2*>(x + (p0 + (long long)(r - 1) * W + (c - 1)) * ldx + cg * 4);
+      const long long rel = ((long long)(r - 1) * W + (c - 1)) * ldx * 2;          // uniform
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) raw[c][r] = *reinterpret_cast<const uint2*>(xb + rel + lane_off);
     }
   }
   if (mul) {
+    const unsigned mlane = (unsigned)((p0 * ldm + cg * 4) * 2);
+    const char* mb = reinterpret_cast<const char*>(mul);
 #pragma unroll
-    for (int it = 0; it < DW_ITER; ++it) mraw[it] = *reinterpret_cast<const uint2*>(mul + (p0 + it) * ldm + cg * 4);
+    for (int it = 0; it < DW_ITER; ++it) mraw[it] = *reinterpret_cast<const uint2*>(mb + (long long)it * ldm * 2 + mlane);
   }
-  float win[3][3][4];                       // [column slot][row dy + 1][channel]
+  srk_f32x2_t win[3][3][2];                     // [column slot][row dy + 1][channel pair]
   auto take_col = [&](int slot, int c) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) unpack4(raw[c][r], win[slot][r]);
+    for (int r = 0; r < 3; ++r) {
+      win[slot][r][0] = srk_f32x2_t{__uint_as_float(raw[c][r].x << 16), __uint_as_float(raw[c][r].x & 0xffff0000u)};
+      win[slot][r][1] = srk_f32x2_t{__uint_as_float(raw[c][r].y << 16), __uint_as_float(raw[c][r].y & 0xffff0000u)};
+    }
   };
   take_col(0, 0);
   take_col(1, 1);
+  const unsigned olane = (unsigned)((p0 * ldo + cg * 4) * 2);
+  char* ob = reinterpret_cast<char*>(out);
 #pragma unroll
   for (int it = 0; it < DW_ITER; ++it) {
-    const long long pix = p0 + it;
     take_col((it + 2) % 3, it + 2);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    srk_f32x2_t acc[2] = {srk_f32x2_t{0.f, 0.f}, srk_f32x2_t{0.f, 0.f}};
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(wr[r * 3 + dx][e], win[(it + dx) % 3][r][e], acc[e]);
-    float m[4] = {1.f, 1.f, 1.f, 1.f};
-    if (mul) unpack4(mraw[it], m);
+        for (int h = 0; h < 2; ++h) acc[h] = __builtin_elementwise_fma(wr[r * 3 + dx][h], win[(it + dx) % 3][r][h], acc[h]);
+    float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = acc[e] * sc[e] + sh[e];
-      if (act == 1) v = gelu_f(v);
-      acc[e] = v * m[e];
+    for (int h = 0; h < 2; ++h) {
+      const srk_f32x2_t a = __builtin_elementwise_fma(acc[h], sc[h], sh[h]);
+      v[2 * h] = a[0];
+      v[2 * h + 1] = a[1];
     }
-    *reinterpret_cast<uint2*>(out + pix * ldo + cg * 4) = make_uint2(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]));
+    if (act == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (mul) {
+      float m[4];
+      unpack4(mraw[it], m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= m[e];
+    }
+    *reinterpret_cast<uint2*>(ob + (long long)it * ldo * 2 + olane) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
   }
 }
 
@@ -325,6 +345,10 @@ int srk_dwconv3x3(const uint16_t* x, int ldx, const float* w, const float* scale
               SRK_E_SHAPE, "dwconv3x3: bad shape / strides (16-byte pieces)");
   SRK_REQUIRE(C8 <= 64, SRK_E_SHAPE, "dwconv3x3: at most 512 channels (got %d)", 8 * C8);
   SRK_REQUIRE(W % DW_ITER == 0, SRK_E_UNSUPPORTED, "dwconv3x3: the image width must be a multiple of %d (got %d)", DW_ITER, W);
+  {
+    const long long ldmax = ldx > ldo ? (ldx > ldm ? ldx : ldm) : (ldo > ldm ? ldo : ldm);
+    SRK_REQUIRE((long long)B * H * W * ldmax * 2 < (1LL << 32), SRK_E_SHAPE, "dwconv3x3: tensors of at most 4 GB (32-bit lane offsets)");
+  }
   const int C4 = 2 * C8;                                               // the kernel's threads own four channels each
   const int py = 256 / C4 < 1 ? 1 : 256 / C4;                          // pixel lanes per workgroup
   const long long npix = (long long)B * H * W;

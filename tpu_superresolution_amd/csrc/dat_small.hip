@@ -14,8 +14,8 @@
 
 namespace {
 
-constexpr int CI_MAX_BC = 6144;     // B * C floats kept in LDS (twice in the backward: 60 KB of static LDS with the [B][S] arrays)
-constexpr int CI_MAX_BS = 768;      // B * S
+constexpr int CI_THREADS = 512;
+constexpr int CI_MAX_LDS = 150 * 1024;      // dynamic LDS of the one workgroup: both weight matrices and every [B][C] / [B][S] array
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -29,141 +29,162 @@ struct CiParams {
   int B, C, S, CA;
 };
 
-// pm -> LDS, y = pm W1^T + b1, batch statistics, a = gelu(BatchNorm(y)); leaves pm [B][C], zh (normalised y) [B][S], a [B][S], rstd [S]
-__device__ void ci_forward_part(const CiParams& p, const float* pm_src, float* pm, float* zh, float* a, float* mean, float* rstd, float* var_out) {
+// LDS layout (floats): W1 [S][C] | W2 [C][S] | pm [B][C] | zh [B][S] | a [B][S] | mean [64] | rstd [64] | var [64]  (+ backward: dpre [B][C] |
+// dy [B][S] | sdg [64] | sdb [64]).  The weights are staged once with coalesced loads: read from global inside the dot-product loops,
+// every thread walked a chain of ~180 L2 round trips (69 us per backward launch).
+struct CiLds {
+  float *W1, *W2, *pm, *zh, *a, *mean, *rstd, *var, *dpre, *dy, *sdg, *sdb;
+};
+__host__ __device__ inline size_t ci_lds_floats(int B, int C, int S, bool bwd) {
+  return (size_t)2 * S * C + (size_t)B * C + 2 * (size_t)B * S + 3 * 64 + (bwd ? (size_t)B * C + (size_t)B * S + 2 * 64 : 0);
+}
+__device__ __forceinline__ CiLds ci_carve(float* base, int B, int C, int S) {
+  CiLds l;
+  l.W1 = base; l.W2 = l.W1 + S * C; l.pm = l.W2 + S * C; l.zh = l.pm + B * C; l.a = l.zh + B * S; l.mean = l.a + B * S; l.rstd = l.mean + 64;
+  l.var = l.rstd + 64; l.dpre = l.var + 64; l.dy = l.dpre + B * C; l.sdg = l.dy + B * S; l.sdb = l.sdg + 64;
+  return l;
+}
+
+// weights + pm -> LDS, y = pm W1^T + b1, batch statistics, a = gelu(BatchNorm(y)); leaves zh (normalised y) [B][S], a [B][S], mean / rstd / var [S]
+__device__ void ci_forward_part(const CiParams& p, const float* pm_src, const CiLds& l) {
   const int tid = threadIdx.x, B = p.B, C = p.C, S = p.S;
-  for (int i = tid; i < B * C; i += 256) {
+  for (int i = tid; i < S * C; i += CI_THREADS) {
+    l.W1[i] = p.W1[i];
+    l.W2[i] = p.W2[i];
+  }
+  for (int i = tid; i < B * C; i += CI_THREADS) {
     const int b = i / C, c = i - b * C;
-    pm[i] = pm_src ? pm_src[i] : p.pooled[(long long)b * p.ldp + p.pad_of[c]] * p.inv_hw;
+    l.pm[i] = pm_src ? pm_src[i] : p.pooled[(long long)b * p.ldp + p.pad_of[c]] * p.inv_hw;
   }
   __syncthreads();
-  for (int i = tid; i < B * S; i += 256) {
+  for (int i = tid; i < B * S; i += CI_THREADS) {
     const int b = i / S, s = i - b * S;
     float acc = p.b1[s];
-    const float* w = p.W1 + (long long)s * C;
-    const float* x = pm + b * C;
+    const float* w = l.W1 + s * C;
+    const float* x = l.pm + b * C;
     for (int c = 0; c < C; ++c) acc = fmaf(x[c], w[c], acc);
-    zh[i] = acc;                                    // y for now
+    l.zh[i] = acc;                                  // y for now
   }
   __syncthreads();
   if (tid < S) {
     float m = 0.f;
-    for (int b = 0; b < B; ++b) m += zh[b * S + tid];
+    for (int b = 0; b < B; ++b) m += l.zh[b * S + tid];
     m /= (float)B;
     float v = 0.f;
     for (int b = 0; b < B; ++b) {
-      const float d = zh[b * S + tid] - m;
+      const float d = l.zh[b * S + tid] - m;
       v = fmaf(d, d, v);
     }
     v /= (float)B;
-    mean[tid] = m;
-    rstd[tid] = rsqrtf(v + p.eps);
-    if (var_out) var_out[tid] = v;
+    l.mean[tid] = m;
+    l.rstd[tid] = rsqrtf(v + p.eps);
+    l.var[tid] = v;
   }
   __syncthreads();
-  for (int i = tid; i < B * S; i += 256) {
+  for (int i = tid; i < B * S; i += CI_THREADS) {
     const int s = i % S;
-    const float z = (zh[i] - mean[s]) * rstd[s];
-    zh[i] = z;
-    a[i] = gelu_f(fmaf(z, p.gamma[s], p.beta[s]));
+    const float z = (l.zh[i] - l.mean[s]) * l.rstd[s];
+    l.zh[i] = z;
+    l.a[i] = gelu_f(fmaf(z, p.gamma[s], p.beta[s]));
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void channel_interaction_fwd_kernel(const CiParams p, float* __restrict__ pm_out, float* __restrict__ cgate,
-                                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                      float momentum) {
-  __shared__ float pm[CI_MAX_BC], zh[CI_MAX_BS], a[CI_MAX_BS], mean[64], rstd[64], var[64];
+__global__ __launch_bounds__(CI_THREADS) void channel_interaction_fwd_kernel(const CiParams p, float* __restrict__ pm_out,
+                                                                             float* __restrict__ cgate, float* __restrict__ running_mean,
+                                                                             float* __restrict__ running_var, float momentum) {
+  extern __shared__ __attribute__((aligned(16))) float ci_smem[];
+  const CiLds l = ci_carve(ci_smem, p.B, p.C, p.S);
   const int tid = threadIdx.x, B = p.B, C = p.C, S = p.S;
-  for (int i = tid; i < B * p.CA; i += 256) cgate[i] = 0.f;          // the padding channels of the gate
-  ci_forward_part(p, nullptr, pm, zh, a, mean, rstd, var);
+  for (int i = tid; i < B * p.CA; i += CI_THREADS) cgate[i] = 0.f;   // the padding channels of the gate
+  ci_forward_part(p, nullptr, l);
   if (running_mean != nullptr && tid < S) {                           // nn.BatchNorm2d's buffers: unbiased variance
-    running_mean[tid] = (1.0f - momentum) * running_mean[tid] + momentum * mean[tid];
-    running_var[tid] = (1.0f - momentum) * running_var[tid] + momentum * var[tid] * ((float)B / fmaxf((float)B - 1.0f, 1.0f));
+    running_mean[tid] = (1.0f - momentum) * running_mean[tid] + momentum * l.mean[tid];
+    running_var[tid] = (1.0f - momentum) * running_var[tid] + momentum * l.var[tid] * ((float)B / fmaxf((float)B - 1.0f, 1.0f));
   }
-  for (int i = tid; i < B * C; i += 256) {
+  for (int i = tid; i < B * C; i += CI_THREADS) {
     const int b = i / C, c = i - b * C;
     float acc = p.b2[c];
-    const float* w = p.W2 + (long long)c * S;
-    const float* x = a + b * S;
+    const float* w = l.W2 + c * S;
+    const float* x = l.a + b * S;
     for (int s = 0; s < S; ++s) acc = fmaf(x[s], w[s], acc);
-    pm_out[i] = pm[i];
+    pm_out[i] = l.pm[i];
     cgate[(long long)b * p.CA + p.pad_of[c]] = sigmoid_f(acc);
   }
 }
 
 // d cgate [B][ldg] (head-padded) -> parameter gradients and d pooled [B][CA] (= d pm / HW, head-padded, padding zero)
-__global__ __launch_bounds__(256) void channel_interaction_bwd_kernel(const CiParams p, const float* __restrict__ pm_in,
-                                                                      const float* __restrict__ dcg, int ldg, float* __restrict__ dW1,
-                                                                      float* __restrict__ db1, float* __restrict__ dgamma,
-                                                                      float* __restrict__ dbeta, float* __restrict__ dW2,
-                                                                      float* __restrict__ db2, float* __restrict__ dpool) {
-  __shared__ float pm[CI_MAX_BC], dpre[CI_MAX_BC], zh[CI_MAX_BS], a[CI_MAX_BS], dy[CI_MAX_BS], mean[64], rstd[64], sdg[64], sdb[64];
+__global__ __launch_bounds__(CI_THREADS) void channel_interaction_bwd_kernel(const CiParams p, const float* __restrict__ pm_in,
+                                                                             const float* __restrict__ dcg, int ldg, float* __restrict__ dW1,
+                                                                             float* __restrict__ db1, float* __restrict__ dgamma,
+                                                                             float* __restrict__ dbeta, float* __restrict__ dW2,
+                                                                             float* __restrict__ db2, float* __restrict__ dpool) {
+  extern __shared__ __attribute__((aligned(16))) float ci_smem[];
+  const CiLds l = ci_carve(ci_smem, p.B, p.C, p.S);
   const int tid = threadIdx.x, B = p.B, C = p.C, S = p.S;
-  for (int i = tid; i < B * p.CA; i += 256) dpool[i] = 0.f;
-  ci_forward_part(p, pm_in, pm, zh, a, mean, rstd, nullptr);
+  for (int i = tid; i < B * p.CA; i += CI_THREADS) dpool[i] = 0.f;
+  ci_forward_part(p, pm_in, l);
   // d(pre-sigmoid) = d cgate * o (1 - o)
-  for (int i = tid; i < B * C; i += 256) {
+  for (int i = tid; i < B * C; i += CI_THREADS) {
     const int b = i / C, c = i - b * C;
     float acc = p.b2[c];
-    const float* w = p.W2 + (long long)c * S;
-    const float* x = a + b * S;
+    const float* w = l.W2 + c * S;
+    const float* x = l.a + b * S;
     for (int s = 0; s < S; ++s) acc = fmaf(x[s], w[s], acc);
     const float o = sigmoid_f(acc);
-    dpre[i] = dcg[(long long)b * ldg + p.pad_of[c]] * o * (1.0f - o);
+    l.dpre[i] = dcg[(long long)b * ldg + p.pad_of[c]] * o * (1.0f - o);
   }
   __syncthreads();
-  for (int i = tid; i < C * S; i += 256) {                            // d W2 [C][S]
+  for (int i = tid; i < C * S; i += CI_THREADS) {                     // d W2 [C][S]
     const int c = i / S, s = i - c * S;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(dpre[b * C + c], a[b * S + s], acc);
+    for (int b = 0; b < B; ++b) acc = fmaf(l.dpre[b * C + c], l.a[b * S + s], acc);
     dW2[i] = acc;
   }
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += CI_THREADS) {
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dpre[b * C + c];
+    for (int b = 0; b < B; ++b) acc += l.dpre[b * C + c];
     db2[c] = acc;
   }
-  for (int i = tid; i < B * S; i += 256) {                            // d a -> d z (through GELU and the BatchNorm affine)
+  for (int i = tid; i < B * S; i += CI_THREADS) {                     // d a -> d z (through GELU and the BatchNorm affine)
     const int b = i / S, s = i - b * S;
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = fmaf(dpre[b * C + c], p.W2[(long long)c * S + s], acc);
-    dy[i] = acc * dgelu_shared_exp(fmaf(zh[i], p.gamma[s], p.beta[s]));            // d(BatchNorm output)
+    for (int c = 0; c < C; ++c) acc = fmaf(l.dpre[b * C + c], l.W2[c * S + s], acc);
+    l.dy[i] = acc * dgelu_shared_exp(fmaf(l.zh[i], p.gamma[s], p.beta[s]));        // d(BatchNorm output)
   }
   __syncthreads();
   if (tid < S) {
     float g = 0.f, bsum = 0.f;
     for (int b = 0; b < B; ++b) {
-      g = fmaf(dy[b * S + tid], zh[b * S + tid], g);
-      bsum += dy[b * S + tid];
+      g = fmaf(l.dy[b * S + tid], l.zh[b * S + tid], g);
+      bsum += l.dy[b * S + tid];
     }
     dgamma[tid] = g;
     dbeta[tid] = bsum;
-    sdg[tid] = g;
-    sdb[tid] = bsum;
+    l.sdg[tid] = g;
+    l.sdb[tid] = bsum;
   }
   __syncthreads();
-  for (int i = tid; i < B * S; i += 256) {                            // BatchNorm backward over the batch: d y
+  for (int i = tid; i < B * S; i += CI_THREADS) {                     // BatchNorm backward over the batch: d y
     const int s = i % S;
-    const float gm = p.gamma[s];
-    dy[i] = gm * rstd[s] * (dy[i] - sdb[s] / (float)B - zh[i] * sdg[s] / (float)B);
+    l.dy[i] = p.gamma[s] * l.rstd[s] * (l.dy[i] - l.sdb[s] / (float)B - l.zh[i] * l.sdg[s] / (float)B);
   }
   __syncthreads();
-  for (int i = tid; i < S * C; i += 256) {                            // d W1 [S][C]
+  for (int i = tid; i < S * C; i += CI_THREADS) {                     // d W1 [S][C]
     const int s = i / C, c = i - s * C;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(dy[b * S + s], pm[b * C + c], acc);
+    for (int b = 0; b < B; ++b) acc = fmaf(l.dy[b * S + s], l.pm[b * C + c], acc);
     dW1[i] = acc;
   }
   if (tid < S) {
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dy[b * S + tid];
+    for (int b = 0; b < B; ++b) acc += l.dy[b * S + tid];
     db1[tid] = acc;
   }
-  for (int i = tid; i < B * C; i += 256) {                            // d pm -> d pooled (/ HW), head-padded
+  for (int i = tid; i < B * C; i += CI_THREADS) {                     // d pm -> d pooled (/ HW), head-padded
     const int b = i / C, c = i - b * C;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc = fmaf(dy[b * S + s], p.W1[(long long)s * C + c], acc);
+    for (int s = 0; s < S; ++s) acc = fmaf(l.dy[b * S + s], l.W1[s * C + c], acc);
     dpool[(long long)b * p.CA + p.pad_of[c]] = acc * p.inv_hw;
   }
 }
@@ -291,18 +312,36 @@ __global__ __launch_bounds__(256) void chan_attn_matrix_bwd_kernel(const float* 
 
 extern "C" {
 
+static int ci_configure(const void* fn, size_t bytes, int* state) {
+  if (*state >= (int)bytes) return SRK_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CI_MAX_LDS) != hipSuccess) {
+    srk_set_error("channel_interaction: cannot reserve %d bytes of LDS", CI_MAX_LDS);
+    return SRK_E_LAUNCH;
+  }
+  *state = CI_MAX_LDS;
+  return SRK_OK;
+}
+
+/* 1 when srk_channel_interaction_fwd / _bwd cover the shape (everything of the one workgroup fits its LDS) */
+int srk_channel_interaction_covered(int B, int C, int S) {
+  return B > 1 && C > 0 && S > 0 && S <= 64 && ci_lds_floats(B, C, S, true) * 4 <= (size_t)CI_MAX_LDS;
+}
+
 int srk_channel_interaction_fwd(const float* pooled, int ldp, float inv_hw, const int* pad_of, const float* W1, const float* b1,
                                 const float* gamma, const float* beta, float eps, const float* W2, const float* b2, float* running_mean,
                                 float* running_var, float momentum, float* pm_out, float* cgate, int B, int C, int S, int CA,
                                 srk_stream_t stream) {
   SRK_REQUIRE(pooled && pad_of && W1 && b1 && gamma && beta && W2 && b2 && pm_out && cgate, SRK_E_NULL, "channel_interaction_fwd: null pointer");
-  REQS(B > 1 && C > 0 && S > 0 && S <= 64 && B * C <= CI_MAX_BC && B * S <= CI_MAX_BS && CA >= C && ldp >= CA &&
-           (running_mean == nullptr) == (running_var == nullptr),
-       "channel_interaction_fwd: B=%d C=%d S=%d (B > 1 as nn.BatchNorm2d in training; B*C <= %d, B*S <= %d, S <= 64)", B, C, S, CI_MAX_BC,
-       CI_MAX_BS);
+  REQS(srk_channel_interaction_covered(B, C, S) && CA >= C && ldp >= CA && (running_mean == nullptr) == (running_var == nullptr),
+       "channel_interaction_fwd: B=%d C=%d S=%d (B > 1 as nn.BatchNorm2d in training; S <= 64; the arrays must fit %d bytes of LDS)", B, C, S,
+       CI_MAX_LDS);
+  static SrkPerDevice<int> st_pd;
+  const size_t lds = ci_lds_floats(B, C, S, false) * 4;
+  const int rc = ci_configure(reinterpret_cast<const void*>(&channel_interaction_fwd_kernel), lds, &st_pd.here());
+  if (rc) return rc;
   CiParams p{pooled, ldp, inv_hw, pad_of, W1, b1, gamma, beta, W2, b2, eps, B, C, S, CA};
-  hipLaunchKernelGGL(channel_interaction_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, pm_out, cgate, running_mean, running_var,
-                     momentum);
+  hipLaunchKernelGGL(channel_interaction_fwd_kernel, dim3(1), dim3(CI_THREADS), lds, (hipStream_t)stream, p, pm_out, cgate, running_mean,
+                     running_var, momentum);
   return srk_check_launch("channel_interaction_fwd");
 }
 
@@ -312,11 +351,14 @@ int srk_channel_interaction_bwd(const float* pm, const float* dcgate, int ldg, f
                                 int CA, srk_stream_t stream) {
   SRK_REQUIRE(pm && dcgate && pad_of && W1 && b1 && gamma && beta && W2 && b2 && dW1 && db1 && dgamma && dbeta && dW2 && db2 && dpool, SRK_E_NULL,
               "channel_interaction_bwd: null pointer");
-  REQS(B > 1 && C > 0 && S > 0 && S <= 64 && B * C <= CI_MAX_BC && B * S <= CI_MAX_BS && CA >= C && ldg >= CA,
-       "channel_interaction_bwd: B=%d C=%d S=%d", B, C, S);
+  REQS(srk_channel_interaction_covered(B, C, S) && CA >= C && ldg >= CA, "channel_interaction_bwd: B=%d C=%d S=%d", B, C, S);
+  static SrkPerDevice<int> st_pd;
+  const size_t lds = ci_lds_floats(B, C, S, true) * 4;
+  const int rc = ci_configure(reinterpret_cast<const void*>(&channel_interaction_bwd_kernel), lds, &st_pd.here());
+  if (rc) return rc;
   CiParams p{nullptr, 0, inv_hw, pad_of, W1, b1, gamma, beta, W2, b2, eps, B, C, S, CA};
-  hipLaunchKernelGGL(channel_interaction_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, pm, dcgate, ldg, dW1, db1, dgamma, dbeta, dW2,
-                     db2, dpool);
+  hipLaunchKernelGGL(channel_interaction_bwd_kernel, dim3(1), dim3(CI_THREADS), lds, (hipStream_t)stream, p, pm, dcgate, ldg, dW1, db1, dgamma,
+                     dbeta, dW2, db2, dpool);
   return srk_check_launch("channel_interaction_bwd");
 }
 

@@ -119,7 +119,7 @@ def _channel_interaction(pm: torch.Tensor, ci: nn.Sequential, stats: Optional[di
 def _ci_fused_ok(B: int, C: int, S: int, ci: nn.Sequential) -> bool:
     """srk_channel_interaction_fwd / _bwd cover this shape (csrc/dat_small.hip limits) and the BatchNorm has a fixed momentum"""
     bn = ci[2]
-    return (B > 1 and S <= 64 and B * C <= 6144 and B * S <= 768 and bn.affine and ci[1].weight.dtype == torch.float32
+    return (bool(lib().srk_channel_interaction_covered(B, C, S)) and bn.affine and ci[1].weight.dtype == torch.float32
             and (not bn.track_running_stats or bn.running_mean is None or (bn.momentum is not None and bn.running_mean.dtype == torch.float32)))
 
 
@@ -508,7 +508,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
         pending.clear()
 
     def conv_wgrad(dyb, xb, conv, Bc, Hc, Wc, CinP, NP, r=1, row_map=None):
-        dw, db = torch.zeros(NP, 9 * CinP, **f32), torch.zeros(NP, **f32)
+        dw, db = ops.zeros_f32((NP, 9 * CinP), dev), ops.zeros_f32((NP,), dev)
         ops._bind_wgrad_workspace(dev)
         if r == 1:
             check(L.srk_conv3x3_wgrad_bf16(dyb.data_ptr(), xb.data_ptr(), dw.data_ptr(), db.data_ptr(), Bc, Hc, Wc, CinP, NP, st))
@@ -519,7 +519,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
         G[pname(conv.bias)] = (db[:Cout] if row_map is None else db[row_map]).contiguous()
 
     def ln_bwd(dyb, x, mean, rstd, norm, gx, gxb, accumulate):
-        dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+        dg, dbt = ops.zeros_f32((C_,), dev), ops.zeros_f32((C_,), dev)
         check(L.srk_layernorm_bwd(dyb.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(), gx.data_ptr(), _ptr(gxb),
                                   dg.data_ptr(), dbt.data_ptr(), T, C_, CP, 1 if accumulate else 0, st))
         G[pname(norm.weight)], G[pname(norm.bias)] = dg, dbt
@@ -762,7 +762,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             lin_wgrad(dqkv, bk["xn1"], at.qkv, row_map=qkv_rows)
             flush_wgrads()            # before the kernel below overwrites gxb2 (the fc2 gradient's operand when no DropPath copy was made)
             if CP in (64, 128, 192):      # qkv dgrad with the norm1 backward in its epilogue (gx2 += d x, gxb2 = its bf16 copy)
-                dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+                dg, dbt = ops.zeros_f32((C_,), dev), ops.zeros_f32((C_,), dev)
                 _gemm(st, _lib.LD_ROWS, _lib.EP_LNBWD, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, outf=gx2, outb=gxb2, ldo=CP,
                       ln=dict(x=bk["x_in"], mean=bk["mean1"], rstd=bk["rstd1"], gamma=blk.norm1.weight, dgamma=dg, dbeta=dbt, C=C_))
                 G[pname(blk.norm1.weight)], G[pname(blk.norm1.bias)] = dg, dbt
@@ -803,7 +803,8 @@ class DATFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         model = ctx.model
-        with torch.cuda.device(dy.device):
+        arena = model.__dict__.setdefault("_zero_arena", ops.ZeroArena())      # the pass's zeroed accumulators: one buffer, one fill
+        with torch.cuda.device(dy.device), ops.arena_scope(arena, dy.device):
             G = dat_backward(model, ctx.saved, dy.contiguous().float(), hook=getattr(model, "grad_sync", None))
         ctx.saved = None
         grads = []

@@ -297,8 +297,8 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
         pending.clear()
 
     def conv_wgrad(dyb, xb, conv, Bc, Hc, Wc, CinP, NP, r=1, row_map=None):
-        dw = torch.zeros(NP, 9 * CinP, **f32)
-        db = torch.zeros(NP, **f32)
+        dw = ops.zeros_f32((NP, 9 * CinP), dev)
+        db = ops.zeros_f32((NP,), dev)
         ops._bind_wgrad_workspace(dev)
         if r == 1:
             check(L.srk_conv3x3_wgrad_bf16(dyb.data_ptr(), xb.data_ptr(), dw.data_ptr(), db.data_ptr(), Bc, Hc, Wc, CinP, NP, st))
@@ -309,7 +309,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
         G[pname(conv.bias)] = (db[:Cout] if row_map is None else db[row_map]).contiguous()
 
     def ln_bwd(dyb, x, mean, rstd, norm, gx, gxb, accumulate):
-        dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+        dg, dbt = ops.zeros_f32((C_,), dev), ops.zeros_f32((C_,), dev)
         check(L.srk_layernorm_bwd(dyb.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(), gx.data_ptr(),
                                   _ptr(gxb), dg.data_ptr(), dbt.data_ptr(), T, C_, CP, 1 if accumulate else 0, st))
         G[pname(norm.weight)], G[pname(norm.bias)] = dg, dbt
@@ -387,7 +387,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             if fused_mlp_bwd_ok:
                 # fc2 dgrad * GELU' -> fc1 dgrad -> norm2 backward in one kernel; the bf16 copy comes out already scaled by the attention
                 # branch's DropPath factor
-                dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+                dg, dbt = ops.zeros_f32((C_,), dev), ops.zeros_f32((C_,), dev)
                 rsc = drop[bk["bidx"], 0] if (hab and drop is not None) else None
                 check(L.srk_mlp_fused_bwd(g_mlp.data_ptr(), PT[pre + "W2T"].data_ptr(), bk["u"].data_ptr(), du.data_ptr(), PT[pre + "W1T"].data_ptr(),
                                           bk["x1"].data_ptr(), bk["mean2"].data_ptr(), bk["rstd2"].data_ptr(), blk.norm2.weight.data_ptr(),
@@ -408,8 +408,8 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                 cab = blk.conv_block.cab
                 att = cab[3].attention
                 Sq = att[1].weight.shape[0]
-                dw1, db1 = torch.zeros(Sq, C_, **f32), torch.zeros(Sq, **f32)
-                dw2, db2 = torch.zeros(C_, Sq, **f32), torch.zeros(C_, **f32)
+                dw1, db1 = ops.zeros_f32((Sq, C_), dev), ops.zeros_f32((Sq,), dev)
+                dw2, db2 = ops.zeros_f32((C_, Sq), dev), ops.zeros_f32((C_,), dev)
                 dmean = torch.empty(B, CP, **f32)
                 dc2 = torch.empty(T, CP, **b16)
                 wsb = torch.empty(max(1, int(L.srk_cab_bwd_workspace(B, HW, CP))), dtype=torch.uint8, device=dev)
@@ -438,7 +438,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             if attn_scratch is None or attn_scratch.numel() < need:
                 attn_scratch = torch.empty(need, dtype=torch.uint8, device=dev)
             dqkv = torch.empty(T, 3 * CA, **b16) if not _POISON else torch.full((T, 3 * CA), float("nan"), **b16)      # every element is written by the attention backward
-            dtab = torch.zeros_like(tab, dtype=torch.float32)
+            dtab = ops.zeros_f32(tab.shape, dev)
             check(L.srk_win256_attention_bwd(bk["qkv"].data_ptr(), 3 * CA, CA, tab.data_ptr(), tab.shape[0], dao.data_ptr(), CA, dqkv.data_ptr(),
                                              dtab.data_ptr(), attn_scratch.data_ptr(), B, H, W, sh, sh, nH, bk["scale"], overlap, st))
             G[pname(tab)] = dtab
@@ -449,7 +449,7 @@ def hat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                 _gemm(st, _lib.LD_ROWS, _lib.EP_RES_BF16, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, res=dxc, outb=dxn1)
                 ln_bwd(dxn1, bk["x_in"], bk["mean1"], bk["rstd1"], blk.norm1, gx2, gxb2, accumulate=True)
             elif CP in (64, 128, 192):      # OCAB: qkv dgrad with the norm1 backward in its epilogue
-                dg, dbt = torch.zeros(C_, **f32), torch.zeros(C_, **f32)
+                dg, dbt = ops.zeros_f32((C_,), dev), ops.zeros_f32((C_,), dev)
                 _gemm(st, _lib.LD_ROWS, _lib.EP_LNBWD, dqkv, PT[pre + "WqkvT"], T, CP, 3 * CA, lda=3 * CA, outf=gx2, outb=gxb2, ldo=CP,
                       ln=dict(x=bk["x_in"], mean=bk["mean1"], rstd=bk["rstd1"], gamma=blk.norm1.weight, dgamma=dg, dbeta=dbt, C=C_))
                 G[pname(blk.norm1.weight)], G[pname(blk.norm1.bias)] = dg, dbt
@@ -487,7 +487,8 @@ class HATFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         model = ctx.model
-        with torch.cuda.device(dy.device):
+        arena = model.__dict__.setdefault("_zero_arena", ops.ZeroArena())      # the pass's zeroed accumulators: one buffer, one fill
+        with torch.cuda.device(dy.device), ops.arena_scope(arena, dy.device):
             G = hat_backward(model, ctx.saved, dy.contiguous().float(), hook=getattr(model, "grad_sync", None))
         ctx.saved = None
         grads = []
