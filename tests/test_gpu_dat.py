@@ -461,7 +461,8 @@ def test_dat_channel_interaction_kernels_vs_autograd(B, C, S, nH):
     assert _rel(dpool[:, hm].cpu(), (grads[0] / HW).cpu()) <= 2e-4 and float(dpool[:, pad].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("wh,ww,shift,H,W", [(8, 32, True, 32, 64), (32, 8, False, 24, 40), (8, 16, True, 24, 40), (16, 8, True, 32, 32)])
+@pytest.mark.parametrize("wh,ww,shift,H,W", [(8, 32, True, 32, 64), (32, 8, False, 24, 40), (8, 16, True, 24, 40), (16, 8, True, 32, 32),
+                                             (16, 16, True, 32, 48)])          # 16 x 16: HAT's W-MSA backward runs through this kernel
 def test_dat_rect_window_attention_backward_vs_autograd(wh, ww, shift, H, W):
     """csrc/attn_rect_bwd.hip against autograd of the oracle's window attention on the padded frame (zero-padded q / k / v, cyclic shift,
     arithmetic mask, dense bias): d q / d k / d v per token and the dense bias gradient."""
