@@ -394,7 +394,8 @@ int srk_mlp_fused_bwd(const uint16_t* g, const uint16_t* w2t, const uint16_t* u,
  * All bf16 operands are row-major [rows][ld] with 8-element (16-byte) aligned rows; C8 = channels / 8. */
 /* backward of srk_win_attention_fwd_padded with a dense bias: d_qkv (q | k | v slices of the heads of this launch) and d_bias
  * [heads][N][N] ACCUMULATED (zero it first) over the windows.  scratch: null (d_bias by float atomics) or
- * srk_win_attention_bwd_padded_scratch bytes (per-window dS tiles + a reduction kernel: the fast path) */
+ * srk_win_attention_bwd_padded_scratch bytes (per-window dS tiles + a reduction kernel, and a transposed copy of the bias for the
+ * key-major pass: the fast path) */
 size_t srk_win_attention_bwd_padded_scratch(int B, int Hp, int Wp, int wh, int ww, int num_heads);
 int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, const uint16_t* d_out, int ldo, uint16_t* d_qkv,
                                  float* d_bias, void* scratch, int B, int H, int W, int Hp, int Wp, int wh, int ww, int shift_y, int shift_x,

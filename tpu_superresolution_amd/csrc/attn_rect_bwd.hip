@@ -35,6 +35,7 @@ struct RectBwdParams {
   bf16_t* dqkv;         // [T][ldq]
   float* dbias;         // [nH][NQ][NQ], accumulated
   float* tiles;         // null, or scratch [windows][nH][NQ][NQ]: every workgroup stores its dS tile, a second kernel sums the windows
+  const float* biasT;   // null, or [nH][NQ(key)][NQ(query)]: the bias transposed (behind the tiles in the scratch) for pass 2, whose lanes are keys
   int ldq, ldo, CA;
   int B, H, W, Hp, Wp;
   int wh, ww, sy, sx;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void win_rect_attn_bwd_kernel(const RectBwd
     return region3r(wy * p.wh + ly, p.Hp, p.wh, p.sy) * 3 + region3r(wx * p.ww + lx, p.Wp, p.ww, p.sx);
   };
   const float* bias_h = p.bias + (long long)h * NQ * NQ;
+  const float* biasT_h = p.biasT ? p.biasT + (long long)h * NQ * NQ : nullptr;
   float* dbias_h = p.tiles ? p.tiles + ((long long)wflat * p.nH + h) * NQ * NQ : p.dbias + (long long)h * NQ * NQ;
   const bool to_tiles = p.tiles != nullptr;
 
@@ -231,12 +233,22 @@ __global__ __launch_bounds__(256, 2) void win_rect_attn_bwd_kernel(const RectBwd
         // sa[e] = q . k of (query 16 qt + 4 g + e, key kl);  da[e] = dO . v of the same pair
         const f32x4_t sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const f32x4_t da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, vf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // bias[q][kl] for the lane's four queries: one 16-byte load from the transposed copy; gathered from the [q][k] layout these
+        // were four dependent-latency scalar loads per MFMA pair, 111 of the kernel's 268 us (null experiment)
+        float bq[4];
+        if (biasT_h) {
+          const float4 bt = *reinterpret_cast<const float4*>(biasT_h + (long long)kl * NQ + 16 * qt + 4 * g);
+          bq[0] = bt.x; bq[1] = bt.y; bq[2] = bt.z; bq[3] = bt.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bq[e] = bias_h[(long long)(16 * qt + 4 * g + e) * NQ + kl];
+        }
         float pv[4], dv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int q = 16 * qt + 4 * g + e;
           const float4 st = *reinterpret_cast<const float4*>(stats + q * 4);
-          float v = sa[e] * p.scale + bias_h[(long long)q * NQ + kl];
+          float v = sa[e] * p.scale + bq[e];
           if (need_mask && label(q) != klab) v += -100.0f;
           pv[e] = __builtin_amdgcn_exp2f(v * L2E - st.x) * st.y;              // P
           dv[e] = pv[e] * (da[e] - st.z);                                      // dS
@@ -282,6 +294,18 @@ __global__ __launch_bounds__(256) void rect_dbias_reduce_kernel(const float* __r
   atomicAdd(dbias + i4 + 3, acc.w);
 }
 
+// biasT[h][k][q] = bias[h][q][k]: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void rect_bias_transpose_kernel(const float* __restrict__ bias, float* __restrict__ biasT, int N) {
+  __shared__ float t[32][33];
+  const int h = blockIdx.z, q0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = bias + (long long)h * N * N;
+  float* dst = biasT + (long long)h * N * N;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = src[(long long)(q0 + r) * N + k0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) dst[(long long)(k0 + r) * N + q0 + tx] = t[tx][r];
+}
+
 template <int QT>
 int launch_rect(const RectBwdParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)4 * 64 * QT * RP * sizeof(bf16_t) + (size_t)64 * QT * 4 * sizeof(float);
@@ -296,7 +320,14 @@ int launch_rect(const RectBwdParams& p, hipStream_t stream) {
   }
   const long long grid = (long long)p.B * p.nWh * p.nWw * p.nH;
   SRK_REQUIRE(grid > 0 && grid < (1LL << 31), SRK_E_SHAPE, "window attention backward: bad grid %lld", grid);
-  hipLaunchKernelGGL((win_rect_attn_bwd_kernel<QT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+  RectBwdParams pp = p;
+  if (p.tiles) {        // the transposed bias lives behind the dS tiles of the scratch (srk_win_attention_bwd_padded_scratch counts it)
+    constexpr int N = 64 * QT;
+    float* bt = p.tiles + grid * N * N;
+    hipLaunchKernelGGL(rect_bias_transpose_kernel, dim3(N / 32, N / 32, p.nH), dim3(256), 0, stream, p.bias, bt, N);
+    pp.biasT = bt;
+  }
+  hipLaunchKernelGGL((win_rect_attn_bwd_kernel<QT>), dim3((unsigned)grid), dim3(256), lds, stream, pp);
   if (p.tiles) {
     const int windows = p.B * p.nWh * p.nWw;
     const long long n = (long long)p.nH * 64 * QT * 64 * QT;
@@ -322,6 +353,6 @@ int srk_launch_win_attn_bwd_padded(const bf16_t* qkv, int ldq, int CA, const flo
   SRK_REQUIRE(sy >= 0 && sy < wh && sx >= 0 && sx < ww, SRK_E_SHAPE, "shift_size must in 0-window_size");
   RectBwdParams p;
   p.qkv = qkv; p.dout = dout; p.bias = bias; p.dqkv = dqkv; p.dbias = dbias; p.tiles = tiles; p.ldq = ldq; p.ldo = ldo; p.CA = CA; p.B = B; p.H = H; p.W = W;
-  p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.sy = sy; p.sx = sx; p.nWh = Hp / wh; p.nWw = Wp / ww; p.nH = nH; p.scale = scale;
+  p.Hp = Hp; p.Wp = Wp; p.wh = wh; p.ww = ww; p.sy = sy; p.sx = sx; p.nWh = Hp / wh; p.nWw = Wp / ww; p.nH = nH; p.scale = scale; p.biasT = nullptr;
   return wh * ww == 256 ? launch_rect<4>(p, stream) : launch_rect<2>(p, stream);
 }

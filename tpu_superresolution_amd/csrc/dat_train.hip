@@ -1002,7 +1002,8 @@ int srk_chan_apply_mat(const float* M, const uint16_t* src, int ldsrc, const flo
 
 size_t srk_win_attention_bwd_padded_scratch(int B, int Hp, int Wp, int wh, int ww, int num_heads) {
   if (B <= 0 || wh <= 0 || ww <= 0 || num_heads <= 0 || Hp % wh || Wp % ww) return 0;
-  return (size_t)B * (Hp / wh) * (Wp / ww) * num_heads * wh * ww * wh * ww * sizeof(float);
+  // one dS tile per (window, head) + the transposed bias [heads][N][N]
+  return ((size_t)B * (Hp / wh) * (Wp / ww) + 1) * num_heads * wh * ww * wh * ww * sizeof(float);
 }
 
 int srk_win_attention_bwd_padded(const uint16_t* qkv, int ldq, int CA, const float* bias, const uint16_t* d_out, int ldo, uint16_t* d_qkv,
