@@ -20,6 +20,8 @@
 //   chan_gram / chan_apply_mat   the channel attention's token reductions and the application of its d x d matrices (:497-508)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -384,6 +386,105 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16_t* __re
         }
       }
     }
+  }
+}
+
+// LDS-tiled form (as dwconv3x3_tile_kernel of dat.hip): one workgroup per (sample, 8 image rows, 64 channels) walks the row band in
+// 16-column tiles; the x halo tile and the dy tile arrive by LDS-DMA, a thread = (4-channel group, tile column) slides a 3 x 3 window
+// down its column (three 8-byte LDS reads + one of dy per pixel) and keeps the ten sums of its four channels in registers.  The register
+// form above issues its four loads per pixel inside the pixel loop: one memory round trip per pixel, 66 us per launch at DAT x4 size.
+constexpr int WT_H = 8, WT_W = 16, WT_CB = 64;
+constexpr int WT_XP = (WT_H + 2) * (WT_W + 2) * 8, WT_YP = WT_H * WT_W * 8;          // 16-byte pieces of the two tiles
+constexpr int WT_XI = (WT_XP + 255) / 256, WT_YI = (WT_YP + 255) / 256;
+__device__ uint4 g_wt_zero[1];
+
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_tile_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                                   float* __restrict__ partial, int H, int W, int C8) {
+  __shared__ __attribute__((aligned(16))) unsigned char xt[WT_XI * 256 * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char yt[WT_YI * 256 * 16];
+  __shared__ float red[4][10][WT_CB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, y0 = blockIdx.x * WT_H, c0 = blockIdx.z * WT_CB;
+  const int CP = C8 * 8;
+  const unsigned xbase = (unsigned)(size_t)xt, ybase = (unsigned)(size_t)yt;
+  const bf16_t* zero16 = reinterpret_cast<const bf16_t*>(g_wt_zero);
+  const int cg = tid & 15, col = tid >> 4;
+  srk_f32x2_t acc[10][2];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t][0] = acc[t][1] = srk_f32x2_t{0.f, 0.f};
+  const int tilesx = (W + WT_W - 1) / WT_W;
+  for (int tx = 0; tx < tilesx; ++tx) {
+    const int x0 = tx * WT_W;
+    if (tx > 0) __syncthreads();                       // the previous tile's readers are done
+#pragma unroll
+    for (int it = 0; it < WT_XI; ++it) {
+      const int p = it * 256 + wave * 64 + lane;
+      const int pix = p >> 3, ch = p & 7;
+      const int py = pix / (WT_W + 2), px = pix - py * (WT_W + 2);
+      const int yy = y0 + py - 1, xx = x0 + px - 1;
+      const bool ok = p < WT_XP && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && c0 + ch * 8 < CP;
+      const bf16_t* src = ok ? x + (((long long)b * H + yy) * W + xx) * ldx + c0 + ch * 8 : zero16;
+      srk_glds16(src, __builtin_amdgcn_readfirstlane(xbase + (unsigned)((it * 256 + wave * 64) * 16)));
+    }
+#pragma unroll
+    for (int it = 0; it < WT_YI; ++it) {
+      const int p = it * 256 + wave * 64 + lane;
+      const int pix = p >> 3, ch = p & 7;
+      const int py = pix / WT_W, px = pix - py * WT_W;
+      const int yy = y0 + py, xx = x0 + px;
+      const bool ok = p < WT_YP && yy < H && xx < W && c0 + ch * 8 < CP;
+      const bf16_t* src = ok ? dy + (((long long)b * H + yy) * W + xx) * lddy + c0 + ch * 8 : zero16;
+      srk_glds16(src, __builtin_amdgcn_readfirstlane(ybase + (unsigned)((it * 256 + wave * 64) * 16)));
+    }
+    srk_wait_vmcnt<0>();
+    __syncthreads();
+    const unsigned char* xl = xt + col * 128 + cg * 8;            // halo pixel (r, col + dx) at + (r * (WT_W + 2) + dx) * 128
+    const unsigned char* yl = yt + col * 128 + cg * 8;            // dy pixel (r, col) at + r * WT_W * 128
+    srk_f32x2_t win[3][3][2];
+    auto take_row = [&](int slot, int r) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const uint2 v = *reinterpret_cast<const uint2*>(xl + (r * (WT_W + 2) + dx) * 128);
+        win[slot][dx][0] = srk_f32x2_t{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+        win[slot][dx][1] = srk_f32x2_t{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+      }
+    };
+    take_row(0, 0);
+    take_row(1, 1);
+#pragma unroll
+    for (int it = 0; it < WT_H; ++it) {
+      take_row((it + 2) % 3, it + 2);
+      const uint2 dv = *reinterpret_cast<const uint2*>(yl + it * WT_W * 128);
+      const srk_f32x2_t d[2] = {srk_f32x2_t{__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u)},
+                                srk_f32x2_t{__uint_as_float(dv.y << 16), __uint_as_float(dv.y & 0xffff0000u)}};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        acc[9][h] += d[h];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) acc[r * 3 + dx][h] = __builtin_elementwise_fma(d[h], win[(it + r) % 3][dx][h], acc[r * 3 + dx][h]);
+      }
+    }
+  }
+  // sum over the 16 tile columns: the wave's four (lanes l, l + 16, l + 32, l + 48), then the four waves through LDS
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float v = acc[t][h][e];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) red[wave][t][cg * 4 + 2 * h + e] = v;
+      }
+  __syncthreads();
+  float* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 10 * CP;
+  for (int i = tid; i < 10 * WT_CB; i += 256) {
+    const int t = i / WT_CB, ch = i - t * WT_CB;
+    if (c0 + ch < CP) dst[t * CP + c0 + ch] = (red[0][t][ch] + red[1][t][ch]) + (red[2][t][ch] + red[3][t][ch]);
   }
 }
 
@@ -886,12 +987,22 @@ int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, c
   return srk_check_launch("mul_bwd");
 }
 
-int srk_dwconv3x3_wgrad_chunks(int H) { return H <= 0 ? 0 : (H + DW_ROWS - 1) / DW_ROWS; }
+static int g_dw_wgrad_tiled = getenv("SRK_DWCONV_TILED") ? atoi(getenv("SRK_DWCONV_TILED")) : 1;     // developer A/B switch (as dat.hip)
+int srk_dwconv3x3_wgrad_chunks(int H) {
+  const int rows = g_dw_wgrad_tiled ? WT_H : DW_ROWS;
+  return H <= 0 ? 0 : (H + rows - 1) / rows;
+}
 
 int srk_dwconv3x3_wgrad(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, float* partial, int B, int H, int W, int C8,
                         srk_stream_t stream) {
   SRK_REQUIRE(dy && x && partial, SRK_E_NULL, "dwconv3x3_wgrad: null pointer");
   REQP(B > 0 && H > 0 && W > 0 && C8 > 0 && C8 <= 64 && lddy % 8 == 0 && ldx % 8 == 0, "dwconv3x3_wgrad: bad shape");
+  if (g_dw_wgrad_tiled) {
+    REQP(B <= 65535, "dwconv3x3_wgrad: at most 65535 samples");
+    hipLaunchKernelGGL(dwconv3x3_wgrad_tile_kernel, dim3((H + WT_H - 1) / WT_H, B, (8 * C8 + WT_CB - 1) / WT_CB), dim3(256), 0, (hipStream_t)stream, dy,
+                       lddy, x, ldx, partial, H, W, C8);
+    return srk_check_launch("dwconv3x3_wgrad (tiled)");
+  }
   hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((H + DW_ROWS - 1) / DW_ROWS, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, partial, H, W,
                      C8);
   return srk_check_launch("dwconv3x3_wgrad");
