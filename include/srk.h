@@ -412,6 +412,9 @@ int srk_chan_stats(const uint16_t* p, int ldp, const uint16_t* q, int ldq, float
  *     -1 for padding (null: identity).
  *   srk_bn_train_bwd_coeffs: partial rows (sum dz, sum dz x) + the forward's coef -> coef [5][ld] = A, B, C of d x = A dz + B x + C,
  *     d gamma, d beta. */
+/* out[o][i] = sum over r < R of in[o][r][i] (in: fp32 [outer][R][n] contiguous), rows added in a fixed order: the finishing sum of the
+ * per-chunk partial rows the token passes above leave behind */
+int srk_sum_rows_f32(const float* in, int outer, int R, int n, float* out, srk_stream_t stream);
 int srk_bn_train_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* gamma, const float* beta, float eps, float* coef,
                         float* running_mean, float* running_var, float momentum, const int* real_of, srk_stream_t stream);
 int srk_bn_train_bwd_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* fwd_coef, float* coef,

@@ -669,3 +669,15 @@ def test_dat_width_180_train_step_vs_oracle():
     for n, b in m.named_buffers():
         if n.endswith("running_var"):
             assert float((b.cpu() - rec[n]).abs().max()) <= 2e-2 * max(float(rec[n].abs().max()), 1e-2), n
+
+
+@pytest.mark.parametrize("outer,R,n", [(1, 256, 16 * 257), (16, 64, 256), (1, 7, 5), (3, 33, 70)])
+def test_dat_sum_rows_kernel_vs_torch(outer, R, n):
+    """srk_sum_rows_f32 (the finishing sum of the per-chunk partial rows of the token passes) against torch.sum, incl. ragged sizes."""
+    check, L = _lib()
+    g = torch.Generator().manual_seed(outer * 100 + R)
+    x = torch.randn(outer, R, n, generator=g).cuda()
+    out = torch.full((outer, n), 7.0, device="cuda")
+    check(L.srk_sum_rows_f32(x.data_ptr(), outer, R, n, out.data_ptr(), _st()))
+    want = x.double().sum(1)
+    assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))

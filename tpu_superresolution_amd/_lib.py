@@ -148,6 +148,7 @@ _SIGNATURES = {
     "srk_channel_interaction_bwd": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srk_chan_attn_matrix_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srk_chan_attn_matrix_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srk_sum_rows_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "srk_bn_train_bwd_coeffs": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "srk_chan_stats_chunks": (_i64, [_i64]),
     "srk_chan_stats": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),

@@ -116,6 +116,28 @@ __device__ __forceinline__ int bn_sum_rows(const float* __restrict__ partial, in
   return (rg == 0 && c < Cn) ? c : -1;
 }
 
+// out[o][i] = sum_r in[o][r][i]: the fixed-order sum of the R partial rows a token pass leaves behind (thread = (row group of 4, column);
+// eight independent loads in flight per thread, row groups combined through LDS).  torch's reduction of the same [R][n] shapes takes
+// ~9.5 us per call, seven calls per DAT block.
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, int R, int n, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
+  const float* base = in + (long long)blockIdx.y * R * n + i;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int r = rg;
+    for (; r + 28 < R; r += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += base[(long long)(r + 4 * u) * n];
+    }
+    for (; r < R; r += 4) a[0] += base[(long long)r * n];
+  }
+  red[rg][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (rg == 0 && i < n) out[(long long)blockIdx.y * n + i] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 // BatchNorm (training) between two token passes, one thread per channel: the R partial rows (rs floats apart; the two sums at + 0 and + ld)
 // of chan_stats / spatial_gate_train are summed in a fixed order, then  mean = s1 / n, var = s2 / n - mean^2, rstd = (var + eps)^-1/2, scale = gamma rstd, shift = beta - mean scale
 // -> coef [4][ld] = scale, shift, mean, rstd; the running estimates move in place as nn.BatchNorm2d's do (momentum, unbiased variance);
@@ -916,6 +938,13 @@ int srk_launch_win_attn_bwd_padded(const bf16_t* qkv, int ldq, int CA, const flo
 extern "C" {
 
 #define REQP(c, ...) SRK_REQUIRE(c, SRK_E_SHAPE, __VA_ARGS__)
+
+int srk_sum_rows_f32(const float* in, int outer, int R, int n, float* out, srk_stream_t stream) {
+  SRK_REQUIRE(in && out, SRK_E_NULL, "sum_rows: null pointer");
+  REQP(outer > 0 && outer <= 65535 && R > 0 && n > 0, "sum_rows: bad shape");
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((n + 63) / 64, outer), dim3(256), 0, (hipStream_t)stream, in, R, n, out);
+  return srk_check_launch("sum_rows");
+}
 
 int srk_bn_train_coeffs(const float* partial, int R, int row_stride, int ld, int C, float n, const float* gamma, const float* beta, float eps, float* coef,
                         float* running_mean, float* running_var, float momentum, const int* real_of, srk_stream_t stream) {

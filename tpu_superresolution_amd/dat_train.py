@@ -116,6 +116,15 @@ def _channel_interaction(pm: torch.Tensor, ci: nn.Sequential, stats: Optional[di
     return torch.sigmoid(F.linear(F.gelu(y), ci[4].weight.flatten(1), ci[4].bias))
 
 
+def _sum_rows(part: torch.Tensor, outer: int, R: int) -> torch.Tensor:
+    """contiguous fp32 [outer][R][...] -> [outer][...] (outer == 1: [...]), rows added in a fixed order by ONE small launch (srk_sum_rows_f32)"""
+    assert part.is_contiguous() and part.dtype == torch.float32
+    n = part.numel() // (outer * R)
+    out = torch.empty(outer, n, dtype=torch.float32, device=part.device)
+    check(lib().srk_sum_rows_f32(part.data_ptr(), outer, R, n, out.data_ptr(), torch.cuda.current_stream(part.device).cuda_stream))
+    return out
+
+
 def _ci_fused_ok(B: int, C: int, S: int, ci: nn.Sequential) -> bool:
     """srk_channel_interaction_fwd / _bwd cover this shape (csrc/dat_small.hip limits) and the BatchNorm has a fixed momentum"""
     bn = ci[2]
@@ -307,7 +316,7 @@ def dat_forward_train(m, x: torch.Tensor, P: Dict[str, torch.Tensor], PT: Dict[s
         """-> (sum p, sum p q) over all tokens [8 C8] or per sample [B][8 C8]"""
         part = torch.empty(B, n_chunks, 2, C8 * 8, **f32)
         check(L.srk_chan_stats(p, ldp, q, ldq, part.data_ptr(), B, HW, C8, st))
-        r = part.sum(1) if per_sample else part.sum((0, 1))
+        r = _sum_rows(part, B, n_chunks).view(B, 2, C8 * 8) if per_sample else _sum_rows(part, 1, B * n_chunks).view(2, C8 * 8)
         return r[..., 0, :], r[..., 1, :]
 
     bidx = 0
@@ -536,7 +545,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
     def token_sums(p, ldp, q, ldq, C8):
         part = torch.empty(B, n_chunks, 2, C8 * 8, **f32)
         check(L.srk_chan_stats(p, ldp, q, ldq, part.data_ptr(), B, HW, C8, st))
-        r = part.sum((0, 1))
+        r = _sum_rows(part, 1, B * n_chunks).view(2, C8 * 8)
         return r[0], r[1]
 
     def dwconv_grads(dyt, lddy, xptr, ldx, CPc, conv, real_rows):
@@ -544,7 +553,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
         nyb = int(L.srk_dwconv3x3_wgrad_chunks(H))
         part = torch.empty(B, nyb, 10, CPc, **f32)
         check(L.srk_dwconv3x3_wgrad(dyt, lddy, xptr, ldx, part.data_ptr(), B, H, W, CPc // 8, st))
-        g = part.sum((0, 1))                                   # [10][CPc]
+        g = _sum_rows(part, 1, B * nyb).view(10, CPc)
         put(conv.weight, g[:9, real_rows].t())
         put(conv.bias, g[9, real_rows])
 
@@ -631,7 +640,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             part = torch.empty(nb, 2, half, **f32)
             check(L.srk_rowln_bwd_bf16(dx2n.data_ptr(), HPh, hh.data_ptr() + HPh * 2, 2 * HPh, sgm.norm.weight.data_ptr(), dhh.data_ptr() + HPh * 2,
                                        2 * HPh, part.data_ptr(), T, half, HPh, st))
-            ps = part.sum(0)
+            ps = _sum_rows(part, 1, nb).view(2, half)
             put(sgm.norm.weight, ps[0])
             put(sgm.norm.bias, ps[1])
             du = torch.empty(T, 2 * HPh, **b16)
@@ -659,7 +668,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             ci_params = [ci[1].weight, ci[1].bias, ci[2].weight, ci[2].bias, ci[4].weight, ci[4].bias]
             S1 = ci[1].weight.shape[0]
             if _ci_fused_ok(B, C_, S1, ci):
-                dcg = dcg_part.sum(1)                                                   # [B][CA], head-padded
+                dcg = _sum_rows(dcg_part, B, nck)                                       # [B][CA], head-padded
                 gci = [torch.empty(p_.shape, **f32) for p_ in ci_params]
                 dpool = torch.empty(B, CA, **f32)
                 check(L.srk_channel_interaction_bwd(bk["pm"].data_ptr(), dcg.data_ptr(), CA, 1.0 / HW, _hm32(hm).data_ptr(), ci[1].weight.data_ptr(),
@@ -690,7 +699,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             part = torch.empty(nblk, 4, 16, **f32)
             check(L.srk_spatial_gate_train(1, tok_src.data_ptr(), CA, w0raw.data_ptr(), b0raw.data_ptr(), si_s.data_ptr(), si_t.data_ptr(), w3.data_ptr(),
                                            dsmap.data_ptr(), None, None, None, None, 0, 0, part.data_ptr(), T, CA, S2, st))
-            ps = part.sum(0)
+            ps = _sum_rows(part, 1, nblk).view(4, 16)
             bc = torch.empty(5, 16, **f32)
             check(L.srk_bn_train_bwd_coeffs(part.data_ptr(), nblk, 64, 16, S2, float(T), si_coef.data_ptr(), bc.data_ptr(), st))
             cA, cB, cC = bc[0], bc[1], bc[2]
@@ -702,7 +711,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
             check(L.srk_spatial_gate_train(2, tok_src.data_ptr(), CA, w0raw.data_ptr(), b0raw.data_ptr(), si_s.data_ptr(), si_t.data_ptr(), w3.data_ptr(),
                                            dsmap.data_ptr(), cA.data_ptr(), cB.data_ptr(), cC.data_ptr(), d_tok_src.data_ptr(), CA, 1, part.data_ptr(), T,
                                            CA, S2, st))
-            ps = part.view(nblk, -1).sum(0)
+            ps = _sum_rows(part, 1, nblk).view(-1)
             put(si[0].weight, ps[:16 * CA].view(16, CA)[:S2][:, hm])
             put(si[0].bias, ps[16 * CA:16 * CA + S2])
             d_att, d_conv = (d_tok_src, d_gate_src) if bk["spatial"] else (d_gate_src, d_tok_src)
@@ -754,7 +763,7 @@ def dat_backward(m, S: dict, dy: torch.Tensor, hook=None) -> Dict[str, torch.Ten
                 check(L.srk_chan_attn_matrix_bwd(part.data_ptr(), part.numel() // (B * nH * 1088), bk["gram"].data_ptr(), bk["A"].data_ptr(),
                                                  temp.data_ptr(), dG.data_ptr(), dGt.data_ptr(), dsq2.data_ptr(), dsk2.data_ptr(), dtemp.data_ptr(), B, nH,
                                                  dh, st))
-                put(at.temperature, dtemp.sum(0))
+                put(at.temperature, _sum_rows(dtemp, 1, B).view(-1))
                 q_ptr, k_ptr = qkv.data_ptr(), qkv.data_ptr() + CA * 2
                 check(L.srk_chan_apply_mat(dG.data_ptr(), k_ptr, 3 * CA, dsq2.data_ptr(), q_ptr, 3 * CA, dqkv.data_ptr(), 3 * CA, B, HW, nH, 0, st))
                 check(L.srk_chan_apply_mat(dGt.data_ptr(), q_ptr, 3 * CA, dsk2.data_ptr(), k_ptr, 3 * CA, dqkv.data_ptr() + CA * 2, 3 * CA, B, HW, nH, 0, st))
