@@ -337,39 +337,66 @@ __global__ __launch_bounds__(256) void dual_gate_combine_kernel(const bf16_t* __
 constexpr int GCH = 256;            // tokens per Gram chunk
 constexpr int GSZ = 32 * 32 + 64;   // partial: G[32][32], |q|^2 [32], |k|^2 [32]
 
-// grid (chunks, heads, B); qkv bf16 [T][ldq], q at column 32 h, k at CA + 32 h
-__global__ __launch_bounds__(256) void chan_gram_partial_kernel(const bf16_t* __restrict__ qkv, int ldq, int CA, float* __restrict__ partial, int N) {
-  __shared__ float qs[GCH][33], ks[GCH][33];
+// Gram partials on the matrix cores, grid (chunks, heads, B): G = x^T y is a [32 x 256] x [256 x 32] product per (chunk, head).  The chunk's x and y rows go to
+// LDS as bf16 [256][40] (16-byte loads, one token row per thread); wave w owns the 16 x 16 output tile (i tile w >> 1, j tile w & 1) and
+// walks the 256 tokens in eight k-steps with transposing LDS reads (ds_read_b64_tr_b16: lane = channel, registers = tokens) for both
+// operands; the two diagonal waves also form x^T x and y^T y, whose diagonals are the squared column norms.  fp32 accumulation of exact
+// bf16 products.  (The VALU form this replaces -- 1088 dot products of length 256 out of padded fp32 LDS tiles -- took 67.7 us per
+// launch at DAT x4 size.)
+constexpr int GP = 40;              // LDS row pitch (elements) of the bf16 tiles
+__global__ __launch_bounds__(256) void chan_gram_mfma_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
+                                                             float* __restrict__ partial, int N) {
+  __shared__ __attribute__((aligned(16))) bf16_t xs[GCH * GP];
+  __shared__ __attribute__((aligned(16))) bf16_t ys[GCH * GP];
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int n0 = chunk * GCH;
   const int tid = threadIdx.x;
-  for (int i = tid; i < GCH * 8; i += 256) {            // 4-channel pieces: 8 per row, q and k
-    const int r = i >> 3, c = (i & 7) * 4;
-    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
-    if (n0 + r < N) {
-      const bf16_t* row = qkv + ((long long)b * N + n0 + r) * ldq + h * 32 + c;
-      const uint2 qu = *reinterpret_cast<const uint2*>(row);
-      const uint2 ku = *reinterpret_cast<const uint2*>(row + CA);
-      unpack_bf2(qu.x, q0, q1); unpack_bf2(qu.y, q2, q3);
-      unpack_bf2(ku.x, k0, k1); unpack_bf2(ku.y, k2, k3);
+  {
+    uint4 xv[4], yv[4];
+    if (n0 + tid < N) {
+      const long long row = (long long)b * N + n0 + tid;
+      const bf16_t* xr = x + row * ldx + h * 32;
+      const bf16_t* yr = y + row * ldy + h * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        xv[c] = *reinterpret_cast<const uint4*>(xr + 8 * c);
+        yv[c] = *reinterpret_cast<const uint4*>(yr + 8 * c);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[c] = yv[c] = make_uint4(0u, 0u, 0u, 0u);
     }
-    qs[r][c] = q0; qs[r][c + 1] = q1; qs[r][c + 2] = q2; qs[r][c + 3] = q3;
-    ks[r][c] = k0; ks[r][c + 1] = k1; ks[r][c + 2] = k2; ks[r][c + 3] = k3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<uint4*>(xs + tid * GP + 8 * c) = xv[c];
+      *reinterpret_cast<uint4*>(ys + tid * GP + 8 * c) = yv[c];
+    }
   }
   __syncthreads();
-  float* o = partial + (((long long)b * gridDim.y + h) * gridDim.x + chunk) * GSZ;
-  for (int p = tid; p < 32 * 32; p += 256) {           // thread owns 4 (i, j) pairs
-    const int i = p >> 5, j = p & 31;
-    float s = 0.f;
-    for (int r = 0; r < GCH; ++r) s = fmaf(qs[r][i], ks[r][j], s);
-    o[p] = s;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int it = wave >> 1, jt = wave & 1;
+  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f}, accx = acc, accy = acc;
+  auto frag = [&](const bf16_t* tile, int ss, int ct) {
+    const bf16x4_t lo = lds_tr_read(tr_addr(tile, GP, 32 * ss + 4 * g, 16 * ct, lane));
+    const bf16x4_t hi = lds_tr_read(tr_addr(tile, GP, 32 * ss + 16 + 4 * g, 16 * ct, lane));
+    return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+#pragma unroll
+  for (int ss = 0; ss < GCH / 32; ++ss) {
+    const bf16x8_t xf = frag(xs, ss, it), yf = frag(ys, ss, jt);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf, acc, 0, 0, 0);          // D[j = 4 g + e][i = r16]
+    if (it == jt) {
+      accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, xf, accx, 0, 0, 0);
+      accy = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, yf, accy, 0, 0, 0);
+    }
   }
-  if (tid < 64) {
-    const int c = tid & 31;
-    float s = 0.f;
-    if (tid < 32) for (int r = 0; r < GCH; ++r) s = fmaf(qs[r][c], qs[r][c], s);
-    else for (int r = 0; r < GCH; ++r) s = fmaf(ks[r][c], ks[r][c], s);
-    o[1024 + tid] = s;
+  float* o = partial + (((long long)b * gridDim.y + h) * gridDim.x + chunk) * GSZ;
+  *reinterpret_cast<float4*>(o + (16 * it + r16) * 32 + 16 * jt + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (it == jt && (r16 >> 2) == g) {
+    const int e = r16 & 3;
+    o[1024 + 16 * it + r16] = e == 0 ? accx[0] : (e == 1 ? accx[1] : (e == 2 ? accx[2] : accx[3]));
+    o[1056 + 16 * jt + r16] = e == 0 ? accy[0] : (e == 1 ? accy[1] : (e == 2 ? accy[2] : accy[3]));
   }
 }
 
@@ -526,6 +553,18 @@ size_t srk_channel_attention_workspace(int B, int N, int num_heads) {
   return ((size_t)B * num_heads * ((N + GCH - 1) / GCH) * GSZ + (size_t)B * num_heads * 1024) * sizeof(float);
 }
 
+}  // extern "C"
+
+// partial [B][heads][chunks][1088] of x^T y, column norms^2 of x and of y per 256-token chunk (head h at column 32 h of each operand)
+int srk_launch_chan_gram(const bf16_t* x, int ldx, const bf16_t* y, int ldy, float* partial, int B, int N, int nH, hipStream_t stream) {
+  SRK_REQUIRE(x && y && partial, SRK_E_NULL, "chan_gram: null pointer");
+  SRK_REQUIRE(B > 0 && B < 65536 && N > 0 && nH > 0 && nH < 65536 && ldx % 8 == 0 && ldy % 8 == 0, SRK_E_SHAPE, "chan_gram: bad shape (16-byte rows)");
+  hipLaunchKernelGGL(chan_gram_mfma_kernel, dim3((N + GCH - 1) / GCH, nH, B), dim3(256), 0, stream, x, ldx, y, ldy, partial, N);
+  return srk_check_launch("chan_gram");
+}
+
+extern "C" {
+
 int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float* temperature, void* workspace, uint16_t* out, int ldo, int B,
                               int N, int num_heads, int head_dim, srk_stream_t stream) {
   SRK_REQUIRE(qkv && temperature && workspace && out, SRK_E_NULL, "channel_attention: null pointer");
@@ -535,7 +574,10 @@ int srk_channel_attention_fwd(const uint16_t* qkv, int ldq, int CA, const float*
   const int nchunk = (N + GCH - 1) / GCH;
   float* partial = static_cast<float*>(workspace);
   float* A = partial + (size_t)B * num_heads * nchunk * GSZ;
-  hipLaunchKernelGGL(chan_gram_partial_kernel, dim3(nchunk, num_heads, B), dim3(256), 0, (hipStream_t)stream, qkv, ldq, CA, partial, N);
+  {
+    const int rc = srk_launch_chan_gram(qkv, ldq, qkv + CA, ldq, partial, B, N, num_heads, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(chan_attn_finish_kernel, dim3(num_heads, B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, head_dim, temperature, A);
   hipLaunchKernelGGL(chan_apply_kernel, dim3((N + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, qkv, ldq, CA, A, num_heads, out, ldo, N);
   return srk_check_launch("channel_attention");

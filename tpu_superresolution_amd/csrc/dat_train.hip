@@ -846,43 +846,6 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const bf16_t* __restrict
 constexpr int TG_CH = 256;            // tokens per Gram chunk
 constexpr int TG_SZ = 32 * 32 + 64;   // partial: G[32][32] = sum_n x[n][i] y[n][j], sum_n x[n][i]^2, sum_n y[n][j]^2
 
-// grid (chunks, heads, B): x, y bf16 [B*N][ld*], head h at column 32 h of each
-__global__ __launch_bounds__(256) void chan_gram2_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
-                                                         float* __restrict__ partial, int N) {
-  __shared__ float xs[TG_CH][33], ys[TG_CH][33];
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int n0 = chunk * TG_CH;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < TG_CH * 8; i += 256) {
-    const int r = i >> 3, c = (i & 7) * 4;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (n0 + r < N) {
-      const long long row = (long long)b * N + n0 + r;
-      const uint2 xu = *reinterpret_cast<const uint2*>(x + row * ldx + h * 32 + c);
-      const uint2 yu = *reinterpret_cast<const uint2*>(y + row * ldy + h * 32 + c);
-      unpack_bf2(xu.x, a0, a1); unpack_bf2(xu.y, a2, a3);
-      unpack_bf2(yu.x, b0, b1); unpack_bf2(yu.y, b2, b3);
-    }
-    xs[r][c] = a0; xs[r][c + 1] = a1; xs[r][c + 2] = a2; xs[r][c + 3] = a3;
-    ys[r][c] = b0; ys[r][c + 1] = b1; ys[r][c + 2] = b2; ys[r][c + 3] = b3;
-  }
-  __syncthreads();
-  float* o = partial + (((long long)b * gridDim.y + h) * gridDim.x + chunk) * TG_SZ;
-  for (int p = tid; p < 32 * 32; p += 256) {
-    const int i = p >> 5, j = p & 31;
-    float s = 0.f;
-    for (int r = 0; r < TG_CH; ++r) s = fmaf(xs[r][i], ys[r][j], s);
-    o[p] = s;
-  }
-  if (tid < 64) {
-    const int c = tid & 31;
-    float s = 0.f;
-    if (tid < 32) for (int r = 0; r < TG_CH; ++r) s = fmaf(xs[r][c], xs[r][c], s);
-    else for (int r = 0; r < TG_CH; ++r) s = fmaf(ys[r][c], ys[r][c], s);
-    o[1024 + tid] = s;
-  }
-}
-
 // out[n][32 h + i] (+)= sum_j M[b][h][i][j] src[n][32 h + j]  (+ dg[b][h][i] * src2[n][32 h + i]) : fp32 matrices, fp32 accumulation
 __global__ __launch_bounds__(256) void chan_apply_mat_kernel(const float* __restrict__ M, const bf16_t* __restrict__ src, int lds_,
                                                              const float* __restrict__ dg, const bf16_t* __restrict__ src2, int lds2,
@@ -1124,10 +1087,7 @@ int64_t srk_chan_gram_floats(int B, int N, int num_heads) { return (int64_t)B * 
 
 // partial [B][heads][chunks][1088]: G = sum_n x[n][i] y[n][j], sum x^2, sum y^2 per 256-token chunk (the caller sums the chunks)
 int srk_chan_gram(const uint16_t* x, int ldx, const uint16_t* y, int ldy, float* partial, int B, int N, int num_heads, srk_stream_t stream) {
-  SRK_REQUIRE(x && y && partial, SRK_E_NULL, "chan_gram: null pointer");
-  REQP(B > 0 && N > 0 && num_heads > 0 && ldx % 4 == 0 && ldy % 4 == 0, "chan_gram: bad shape");
-  hipLaunchKernelGGL(chan_gram2_kernel, dim3((N + TG_CH - 1) / TG_CH, num_heads, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, partial, N);
-  return srk_check_launch("chan_gram");
+  return srk_launch_chan_gram(x, ldx, y, ldy, partial, B, N, num_heads, (hipStream_t)stream);      // csrc/dat.hip (matrix cores)
 }
 
 // out[n][32 h + i] (+)= sum_j M[b][h][i][j] src[n][32 h + j] + diag[b][h][i] src2[n][32 h + i]

@@ -73,3 +73,5 @@ int srk_launch_adamw(float* p, const float* g, float* m, float* v, long long n, 
 int srk_launch_probe_trread(const bf16_t* in, bf16_t* out, hipStream_t stream);
 int srk_launch_win256_attn_fwd(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W, int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream);
 int srk_launch_win_attn_fwd_padded(const bf16_t* qkv, int ldq, int CA, const float* bias, int table_rows, bf16_t* out, int ldo, int B, int H, int W, int Hp, int Wp, int wh, int ww, int sy, int sx, int nH, float scale, int overlap, hipStream_t stream);
+// dat.hip: Gram partials of the channel attention on the matrix cores (also behind srk_chan_gram of dat_train.hip)
+int srk_launch_chan_gram(const bf16_t* x, int ldx, const bf16_t* y, int ldy, float* partial, int B, int N, int nH, hipStream_t stream);
