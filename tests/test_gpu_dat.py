@@ -681,3 +681,19 @@ def test_dat_sum_rows_kernel_vs_torch(outer, R, n):
     check(L.srk_sum_rows_f32(x.data_ptr(), outer, R, n, out.data_ptr(), _st()))
     want = x.double().sum(1)
     assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("rows,Cn,CPo,ld", [(300, 360, 384, 768), (1000, 180, 192, 384), (77, 90, 96, 192), (5, 30, 32, 64)])
+def test_dat_row_layernorm_all_lane_groupings(rows, Cn, CPo, ld):
+    """srk_rowln_bf16 with 64 / 32 / 16 lanes per row (C <= 512 / 256 / 128), ragged row counts, column slices, zero padding up to CP_out."""
+    check, L = _lib()
+    g = torch.Generator().manual_seed(rows + Cn)
+    h = torch.randn(rows, ld, generator=g).to(torch.bfloat16)
+    gm, bt = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.1
+    off = ld - CPo                                            # a column slice that ends at the row's end (16-byte aligned)
+    want = F.layer_norm(h.float()[:, off:off + Cn], (Cn,), gm, bt, 1e-5)
+    hd, gd, bd = h.cuda(), gm.cuda(), bt.cuda()
+    o = torch.full((rows, CPo), 7.0, dtype=torch.bfloat16, device="cuda")
+    check(L.srk_rowln_bf16(hd.data_ptr() + off * 2, ld, gd.data_ptr(), bd.data_ptr(), o.data_ptr(), CPo, rows, Cn, CPo, _st()))
+    got = o.cpu().float()
+    assert float((got[:, :Cn] - want).abs().max()) <= 3e-2 and float(got[:, Cn:].abs().max()) == 0.0
