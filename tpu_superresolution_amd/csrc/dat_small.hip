@@ -214,27 +214,31 @@ __global__ __launch_bounds__(256) void chan_attn_matrix_fwd_kernel(const float* 
   }
   __syncthreads();
   const float t = temp[h];
-  for (int i = tid; i < 32; i += 256) {
-    float* row = A + ((long long)bh * 32 + i) * 32;
-    if (i >= dh) {
-      for (int j = 0; j < 32; ++j) row[j] = 0.f;
-      continue;
-    }
-    const float nq = sqrtf(fmaxf(g[1024 + i], 1e-24f));             // F.normalize: norm clamped at 1e-12
-    float l[32], mx = -3.0e38f;
-    for (int j = 0; j < dh; ++j) {
-      const float nk = sqrtf(fmaxf(g[1056 + j], 1e-24f));
-      l[j] = g[i * 32 + j] / (nq * nk) * t;
-      mx = fmaxf(mx, l[j]);
-    }
-    float sum = 0.f;
-    for (int j = 0; j < dh; ++j) {
-      l[j] = __expf(l[j] - mx);
-      sum += l[j];
-    }
-    const float inv = 1.0f / sum;
-    for (int j = 0; j < 32; ++j) row[j] = j < dh ? l[j] * inv : 0.f;
+  // thread = (row i, four columns); the row's max / sum through three lane exchanges over its eight threads
+  const int i = tid >> 3, j0 = (tid & 7) * 4;
+  const float nq = sqrtf(fmaxf(g[1024 + i], 1e-24f));               // F.normalize: norm clamped at 1e-12
+  float l[4], mx = -3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = j0 + e;
+    const float nk = sqrtf(fmaxf(g[1056 + j], 1e-24f));
+    l[e] = (i < dh && j < dh) ? g[i * 32 + j] / (nq * nk) * t : -3.0e38f;
+    mx = fmaxf(mx, l[e]);
   }
+  mx = fmaxf(mx, __shfl_xor(mx, 1));
+  mx = fmaxf(mx, __shfl_xor(mx, 2));
+  mx = fmaxf(mx, __shfl_xor(mx, 4));
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    l[e] = (i < dh && j0 + e < dh) ? __expf(l[e] - mx) : 0.f;
+    sum += l[e];
+  }
+  sum += __shfl_xor(sum, 1);
+  sum += __shfl_xor(sum, 2);
+  sum += __shfl_xor(sum, 4);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  *reinterpret_cast<float4*>(A + ((long long)bh * 32 + i) * 32 + j0) = make_float4(l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv);
 }
 
 // d A (chunk partials of the Gram kernel run on (d out, v)) -> d G, d G^T, 2 d(sum q^2), 2 d(sum k^2) (the diagonal coefficients of
