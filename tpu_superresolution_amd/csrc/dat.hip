@@ -12,8 +12,6 @@
 //                           temperature, softmax, applied to v -- Gram partials per 256-token chunk, fixed-order finish
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "common.h"
 #include "kernels.h"
 
@@ -29,117 +27,17 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
 }
 
-// threadIdx.x = 4-channel group, threadIdx.y = pixel lane; the thread keeps its group's 36 weights + scale / shift in registers and walks
-// DW_ITER consecutive pixels of one image row with a sliding 3 x 3 register window (a first version re-read weights and all nine
-// neighbours per pixel: 350 us per launch at cfg5, 53 % of the DAT forward; eight channels per thread needed 188 VGPRs -- two waves
-// per SIMD under a chain of load -> unpack -> fma latencies, 63 us -- four need ~100).
-// w: fp32 [C4*4][9] (zero rows for pad channels), scale / shift: fp32 [C4*4]
-constexpr int DW_ITER = 8;
 __device__ __forceinline__ void unpack4(const uint2& v, float (&f)[4]) {
   unpack_bf2(v.x, f[0], f[1]);
   unpack_bf2(v.y, f[2], f[3]);
 }
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        const bf16_t* __restrict__ mul, int ldm, bf16_t* __restrict__ out, int ldo, int B,
-                                                        int H, int W, int C4, int act) {
-  __shared__ float wsh[128 * 4 * 11];           // per channel: 9 taps, scale, shift (coalesced cooperative load, then registers)
-  const int nthr = blockDim.x * blockDim.y, lt = threadIdx.y * blockDim.x + threadIdx.x;
-  for (int i = lt; i < C4 * 4 * 9; i += nthr) wsh[(i / 9) * 11 + i % 9] = w[i];
-  for (int i = lt; i < C4 * 4; i += nthr) {
-    wsh[i * 11 + 9] = scale[i];
-    wsh[i * 11 + 10] = shift[i];
-  }
-  __syncthreads();
-  const int cg = threadIdx.x;
-  // two channels per VALU lane-operation (v_pk_fma_f32): the 36 multiply-adds per pixel are the kernel's largest instruction block
-  srk_f32x2_t wr[9][2], sc[2], sh[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t][h] = srk_f32x2_t{wsh[(cg * 4 + 2 * h) * 11 + t], wsh[(cg * 4 + 2 * h + 1) * 11 + t]};
-    sc[h] = srk_f32x2_t{wsh[(cg * 4 + 2 * h) * 11 + 9], wsh[(cg * 4 + 2 * h + 1) * 11 + 9]};
-    sh[h] = srk_f32x2_t{wsh[(cg * 4 + 2 * h) * 11 + 10], wsh[(cg * 4 + 2 * h + 1) * 11 + 10]};
-  }
-  const long long npix = (long long)B * H * W;
-  const long long p0 = ((long long)blockIdx.x * blockDim.y + threadIdx.y) * DW_ITER;
-  if (p0 >= npix) return;
-  // the thread's DW_ITER pixels lie in one image row (W % DW_ITER == 0, checked by the launcher): a 3 x 3 register window slides along
-  // x, so every step loads one new column (3 x 8 bytes) instead of nine pieces
-  const int x0 = (int)(p0 % W);
-  const int y = (int)((p0 / W) % H);
-  // every load of the segment is issued before the first use: (DW_ITER + 2) columns x 3 rows of 8 bytes (+ the gating operand) stay
-  // packed in registers; a load placed next to its use paid one memory round trip per pixel (2-3 us each, 87 us per launch).
-  // Addresses: one 32-bit byte offset per lane (the launcher bounds the tensor by 4 GB) + a wave-uniform offset per (row, column) --
-  // as 64-bit per-load arithmetic the address computation was a quarter of the kernel's instructions.
-  const unsigned lane_off = (unsigned)((p0 * ldx + cg * 4) * 2);
-  const char* xb = reinterpret_cast<const char*>(x);
-  uint2 raw[DW_ITER + 2][3], mraw[DW_ITER];
-#pragma unroll
-  for (int c = 0; c < DW_ITER + 2; ++c) {
-    const int xx = x0 + c - 1;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int yy = y + r - 1;
-      raw[c][r] = make_uint2(0u, 0u);
-      const long long rel = ((long long)(r - 1) * W + (c - 1)) * ldx * 2;          // uniform
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) raw[c][r] = *reinterpret_cast<const uint2*>(xb + rel + lane_off);
-    }
-  }
-  if (mul) {
-    const unsigned mlane = (unsigned)((p0 * ldm + cg * 4) * 2);
-    const char* mb = reinterpret_cast<const char*>(mul);
-#pragma unroll
-    for (int it = 0; it < DW_ITER; ++it) mraw[it] = *reinterpret_cast<const uint2*>(mb + (long long)it * ldm * 2 + mlane);
-  }
-  srk_f32x2_t win[3][3][2];                     // [column slot][row dy + 1][channel pair]
-  auto take_col = [&](int slot, int c) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      win[slot][r][0] = srk_f32x2_t{__uint_as_float(raw[c][r].x << 16), __uint_as_float(raw[c][r].x & 0xffff0000u)};
-      win[slot][r][1] = srk_f32x2_t{__uint_as_float(raw[c][r].y << 16), __uint_as_float(raw[c][r].y & 0xffff0000u)};
-    }
-  };
-  take_col(0, 0);
-  take_col(1, 1);
-  const unsigned olane = (unsigned)((p0 * ldo + cg * 4) * 2);
-  char* ob = reinterpret_cast<char*>(out);
-#pragma unroll
-  for (int it = 0; it < DW_ITER; ++it) {
-    take_col((it + 2) % 3, it + 2);
-    srk_f32x2_t acc[2] = {srk_f32x2_t{0.f, 0.f}, srk_f32x2_t{0.f, 0.f}};
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) acc[h] = __builtin_elementwise_fma(wr[r * 3 + dx][h], win[(it + dx) % 3][r][h], acc[h]);
-    float v[4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const srk_f32x2_t a = __builtin_elementwise_fma(acc[h], sc[h], sh[h]);
-      v[2 * h] = a[0];
-      v[2 * h + 1] = a[1];
-    }
-    if (act == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-    }
-    if (mul) {
-      float m[4];
-      unpack4(mraw[it], m);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= m[e];
-    }
-    *reinterpret_cast<uint2*>(ob + (long long)it * ldo * 2 + olane) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-  }
-}
 
-// LDS-tiled form of the same op: a workgroup owns an 8 x 16 pixel tile of 64 channels.  The 10 x 18 halo tile (23 KB) arrives by LDS-DMA
-// -- every input element is fetched once per tile (1.4 x with the halo) instead of 3.75 8-byte loads per output from L1 / L2, and no
-// registers hold loads in flight: the register form above runs at three waves per SIMD and is bound by the latency of its 30 loads per
-// thread (31.6 us per launch at DAT x4 size for 67 MB of compulsory traffic).  Thread = (4-channel group, tile column): it walks the
-// eight rows of its column with a 3 x 3 window of packed pairs that takes three 8-byte LDS reads per output (a wave reads 512
+// Depth-wise 3 x 3 conv (+ folded bias / BatchNorm affine, optional GELU, optional gating multiply), LDS-tiled: a workgroup owns an 8 x 16
+// pixel tile of 64 channels.  w: fp32 [C][9] (zero rows for pad channels), scale / shift: fp32 [C].  The 10 x 18 halo tile (23 KB) arrives
+// by LDS-DMA -- every input element is fetched once per tile (1.4 x with the halo), and no registers hold loads in flight.  (Earlier
+// forms: nine neighbour loads + weight re-reads per pixel, 350 us per launch at cfg5; then a register form with a sliding window that
+// issued its 30 loads per thread up front and ran at three waves per SIMD, 31.6 us for 67 MB of compulsory traffic.)
+// Thread = (4-channel group, tile column): it walks the eight rows of its column with a 3 x 3 window of packed pairs that takes three 8-byte LDS reads per output (a wave reads 512
 // contiguous bytes: conflict-free).  Any H, W (edges are predicated); channels beyond C read zeros and are not stored.
 constexpr int DT_H = 8, DT_W = 16, DT_CB = 64;
 constexpr int DT_HH = DT_H + 2, DT_HW = DT_W + 2;
@@ -500,34 +398,17 @@ inline int grid_for(long long n, int block = 256, int cap = 16384) {
 
 extern "C" {
 
-static int g_dw_tiled = getenv("SRK_DWCONV_TILED") ? atoi(getenv("SRK_DWCONV_TILED")) : 1;     // developer A/B switch
-
 int srk_dwconv3x3(const uint16_t* x, int ldx, const float* w, const float* scale, const float* shift, const uint16_t* mul, int ldm, uint16_t* out,
                   int ldo, int B, int H, int W, int C8, int act, srk_stream_t stream) {
   SRK_REQUIRE(x && w && scale && shift && out, SRK_E_NULL, "dwconv3x3: null pointer");
   SRK_REQUIRE(B > 0 && H > 0 && W > 0 && C8 > 0 && ldx >= 8 * C8 && ldo >= 8 * C8 && ldx % 8 == 0 && ldo % 8 == 0 && (mul == nullptr || ldm % 8 == 0),
               SRK_E_SHAPE, "dwconv3x3: bad shape / strides (16-byte pieces)");
   SRK_REQUIRE(C8 <= 64, SRK_E_SHAPE, "dwconv3x3: at most 512 channels (got %d)", 8 * C8);
-  if (g_dw_tiled) {                                                       // LDS-tiled form: any H, W
-    const int tilesx = (W + DT_W - 1) / DT_W, tilesy = (H + DT_H - 1) / DT_H;
-    const long long nb = (long long)B * tilesx * tilesy;
-    SRK_REQUIRE(nb < (1LL << 31), SRK_E_SHAPE, "dwconv3x3: too many tiles");
-    hipLaunchKernelGGL(dwconv3x3_tile_kernel, dim3((unsigned)nb, (unsigned)((8 * C8 + DT_CB - 1) / DT_CB)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
-                       scale, shift, mul, ldm, out, ldo, B, H, W, 8 * C8, act, tilesx, tilesy);
-    return srk_check_launch("dwconv3x3 (tiled)");
-  }
-  SRK_REQUIRE(W % DW_ITER == 0, SRK_E_UNSUPPORTED, "dwconv3x3: the image width must be a multiple of %d (got %d)", DW_ITER, W);
-  {
-    const long long ldmax = ldx > ldo ? (ldx > ldm ? ldx : ldm) : (ldo > ldm ? ldo : ldm);
-    SRK_REQUIRE((long long)B * H * W * ldmax * 2 < (1LL << 32), SRK_E_SHAPE, "dwconv3x3: tensors of at most 4 GB (32-bit lane offsets)");
-  }
-  const int C4 = 2 * C8;                                               // the kernel's threads own four channels each
-  const int py = 256 / C4 < 1 ? 1 : 256 / C4;                          // pixel lanes per workgroup
-  const long long npix = (long long)B * H * W;
-  const long long blocks = (npix + (long long)py * DW_ITER - 1) / ((long long)py * DW_ITER);
-  SRK_REQUIRE(blocks < (1LL << 31), SRK_E_SHAPE, "dwconv3x3: too many pixels");
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(C4, py), 0, (hipStream_t)stream, x, ldx, w, scale, shift, mul, ldm, out, ldo, B,
-                     H, W, C4, act);
+  const int tilesx = (W + DT_W - 1) / DT_W, tilesy = (H + DT_H - 1) / DT_H;       // any H, W: edges are predicated
+  const long long nb = (long long)B * tilesx * tilesy;
+  SRK_REQUIRE(nb < (1LL << 31), SRK_E_SHAPE, "dwconv3x3: too many tiles");
+  hipLaunchKernelGGL(dwconv3x3_tile_kernel, dim3((unsigned)nb, (unsigned)((8 * C8 + DT_CB - 1) / DT_CB)), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
+                     scale, shift, mul, ldm, out, ldo, B, H, W, 8 * C8, act, tilesx, tilesy);
   return srk_check_launch("dwconv3x3");
 }
 

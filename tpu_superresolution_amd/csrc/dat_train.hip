@@ -20,15 +20,12 @@
 //   chan_gram / chan_apply_mat   the channel attention's token reductions and the application of its d x d matrices (:497-508)
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int ST_ROWS = 256;     // tokens per workgroup of the reduction passes
-constexpr int DW_ROWS = 2;       // image rows per workgroup of the depth-wise weight gradient (B * H / 2 workgroups fill the chip at 64 x 64)
 
 inline int grid_cap(long long n, int block = 256, int cap = 16384) {
   long long g = (n + block - 1) / block;
@@ -335,86 +332,10 @@ __global__ __launch_bounds__(256) void mul_bwd_kernel(const bf16_t* __restrict__
 }
 
 // depth-wise 3x3 (pad 1) weight gradient: partial[chunk][tap][c] = sum over the chunk's pixels of dy[pix][c] x[pix + off(tap)][c],
-// partial[chunk][9][c] = sum dy.  One workgroup per (sample, DW_ROWS image rows); thread = 8-channel piece x pixel lane.
-__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
-                                                              float* __restrict__ partial, int H, int W, int C8) {
-  __shared__ float red[8][10][8 * 32 / 8 + 1];      // [lane][tap][channel of the piece group]  (re-used per piece group)
-  const int b = blockIdx.y, y0 = blockIdx.x * DW_ROWS;
-  const int nyb = gridDim.x;
-  const int tid = threadIdx.x;
-  const int CP = C8 * 8;
-  float* dst = partial + ((long long)b * nyb + blockIdx.x) * 10 * CP;
-  for (int c0 = 0; c0 < C8; c0 += 32) {
-    const int piece = c0 + tid % 32, pl = tid / 32;        // 8 pixel lanes
-    float acc[10][8];
-#pragma unroll
-    for (int tp = 0; tp < 10; ++tp)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[tp][e] = 0.f;
-    if (piece < C8) {
-      // a lane walks a run of consecutive pixels of an image row with the 3 x 3 neighbourhood of x in registers: per pixel one new
-      // column of x (3 loads) and dy instead of 9 + 1 loads
-      const int seg = (W + 7) / 8, x_begin = pl * seg, x_end = min(W, x_begin + seg);
-      auto load8 = [&](const bf16_t* base, int ld, int yy, int xx, float (&v)[8]) {
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-          const uint4 u = *reinterpret_cast<const uint4*>(base + (((long long)b * H + yy) * W + xx) * ld + piece * 8);
-          unpack_bf2(u.x, v[0], v[1]); unpack_bf2(u.y, v[2], v[3]); unpack_bf2(u.z, v[4], v[5]); unpack_bf2(u.w, v[6], v[7]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-      };
-      for (int yy = y0; yy < y0 + DW_ROWS && yy < H; ++yy) {
-        float win[3][3][8];                  // [row dy + 1][column dx + 1]
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          load8(x, ldx, yy + r - 1, x_begin - 1, win[r][1]);      // becomes column dx = -1 after the first shift
-          load8(x, ldx, yy + r - 1, x_begin, win[r][2]);
-        }
-        for (int xx = x_begin; xx < x_end; ++xx) {
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              win[r][0][e] = win[r][1][e];
-              win[r][1][e] = win[r][2][e];
-            }
-            load8(x, ldx, yy + r - 1, xx + 1, win[r][2]);
-          }
-          float d[8];
-          load8(dy, lddy, yy, xx, d);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[9][e] += d[e];
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[tp][e] += d[e] * win[tp / 3][tp % 3][e];
-        }
-      }
-    }
-    // combine the 8 pixel lanes of a piece (lanes tid % 32 == const): through LDS, one channel octet at a time
-    for (int e = 0; e < 8; ++e) {
-      __syncthreads();
-#pragma unroll
-      for (int tp = 0; tp < 10; ++tp) red[pl][tp][tid % 32] = acc[tp][e];
-      __syncthreads();
-      if (pl == 0 && piece < C8) {
-#pragma unroll
-        for (int tp = 0; tp < 10; ++tp) {
-          float s = 0.f;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) s += red[k][tp][tid % 32];
-          dst[tp * CP + piece * 8 + e] = s;
-        }
-      }
-    }
-  }
-}
-
-// LDS-tiled form (as dwconv3x3_tile_kernel of dat.hip): one workgroup per (sample, 8 image rows, 64 channels) walks the row band in
-// 16-column tiles; the x halo tile and the dy tile arrive by LDS-DMA, a thread = (4-channel group, tile column) slides a 3 x 3 window
-// down its column (three 8-byte LDS reads + one of dy per pixel) and keeps the ten sums of its four channels in registers.  The register
-// form above issues its four loads per pixel inside the pixel loop: one memory round trip per pixel, 66 us per launch at DAT x4 size.
+// partial[chunk][9][c] = sum dy (chunk = (sample, band of 8 image rows)).  LDS-tiled as dwconv3x3_tile_kernel of dat.hip: one workgroup
+// per (sample, 8 image rows, 64 channels) walks the row band in 16-column tiles; the x halo tile and the dy tile arrive by LDS-DMA, a thread = (4-channel group, tile column) slides a 3 x 3 window
+// down its column (three 8-byte LDS reads + one of dy per pixel) and keeps the ten sums of its four channels in registers.  (The register
+// form before it issued its four loads per pixel inside the pixel loop: one memory round trip per pixel, 66 us per launch at DAT x4 size.)
 constexpr int WT_H = 8, WT_W = 16, WT_CB = 64;
 constexpr int WT_XP = (WT_H + 2) * (WT_W + 2) * 8, WT_YP = WT_H * WT_W * 8;          // 16-byte pieces of the two tiles
 constexpr int WT_XI = (WT_XP + 255) / 256, WT_YI = (WT_YP + 255) / 256;
@@ -979,24 +900,15 @@ int srk_mul_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* a, int lda, c
   return srk_check_launch("mul_bwd");
 }
 
-static int g_dw_wgrad_tiled = getenv("SRK_DWCONV_TILED") ? atoi(getenv("SRK_DWCONV_TILED")) : 1;     // developer A/B switch (as dat.hip)
-int srk_dwconv3x3_wgrad_chunks(int H) {
-  const int rows = g_dw_wgrad_tiled ? WT_H : DW_ROWS;
-  return H <= 0 ? 0 : (H + rows - 1) / rows;
-}
+int srk_dwconv3x3_wgrad_chunks(int H) { return H <= 0 ? 0 : (H + WT_H - 1) / WT_H; }
 
 int srk_dwconv3x3_wgrad(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, float* partial, int B, int H, int W, int C8,
                         srk_stream_t stream) {
   SRK_REQUIRE(dy && x && partial, SRK_E_NULL, "dwconv3x3_wgrad: null pointer");
   REQP(B > 0 && H > 0 && W > 0 && C8 > 0 && C8 <= 64 && lddy % 8 == 0 && ldx % 8 == 0, "dwconv3x3_wgrad: bad shape");
-  if (g_dw_wgrad_tiled) {
-    REQP(B <= 65535, "dwconv3x3_wgrad: at most 65535 samples");
-    hipLaunchKernelGGL(dwconv3x3_wgrad_tile_kernel, dim3((H + WT_H - 1) / WT_H, B, (8 * C8 + WT_CB - 1) / WT_CB), dim3(256), 0, (hipStream_t)stream, dy,
-                       lddy, x, ldx, partial, H, W, C8);
-    return srk_check_launch("dwconv3x3_wgrad (tiled)");
-  }
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((H + DW_ROWS - 1) / DW_ROWS, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, partial, H, W,
-                     C8);
+  REQP(B <= 65535, "dwconv3x3_wgrad: at most 65535 samples");
+  hipLaunchKernelGGL(dwconv3x3_wgrad_tile_kernel, dim3((H + WT_H - 1) / WT_H, B, (8 * C8 + WT_CB - 1) / WT_CB), dim3(256), 0, (hipStream_t)stream, dy,
+                     lddy, x, ldx, partial, H, W, C8);
   return srk_check_launch("dwconv3x3_wgrad");
 }
 
