@@ -545,6 +545,17 @@ __global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* _
   }
   float* dyl = red;                      // [16 tokens][16]
   float* xs = red + 256;                 // [16 tokens][C]
+  // the token row (and its dsmap) of step it + 1 is requested while step it computes: loaded at the top of its own step, every one of
+  // the 16 steps began with an exposed memory round trip (52 % of the wave-cycles parked)
+  uint2 un[NV];
+  float dsn = 0.f;
+  auto fetch = [&](int it) {
+    const long long tn = (long long)blockIdx.x * 256 + it * 16 + grp;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) un[i] = tn < rows ? *reinterpret_cast<const uint2*>(x + tn * ldx + 64 * i + 4 * j) : make_uint2(0u, 0u);
+    if constexpr (WHAT != 0) dsn = tn < rows ? dsmap[tn] : 0.f;
+  };
+  fetch(0);
 #pragma unroll 1
   for (int it = 0; it < 16; ++it) {
     const long long t = (long long)blockIdx.x * 256 + it * 16 + grp;
@@ -552,11 +563,11 @@ __global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* _
     float xv[NV][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      uint2 u = make_uint2(0, 0);
-      if (ok) u = *reinterpret_cast<const uint2*>(x + t * ldx + 64 * i + 4 * j);
-      unpack_bf2(u.x, xv[i][0], xv[i][1]);
-      unpack_bf2(u.y, xv[i][2], xv[i][3]);
+      unpack_bf2(un[i].x, xv[i][0], xv[i][1]);
+      unpack_bf2(un[i].y, xv[i][2], xv[i][3]);
     }
+    const float ds_cur = dsn;
+    if (it + 1 < 16) fetch(it + 1);
     float y1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(256) void spatial_gate_train_kernel(const bf16_t* _
         acc[1][s] += ok ? y1[s] * y1[s] : 0.f;
       }
     } else {
-      const float ds = ok ? dsmap[t] : 0.f;
+      const float ds = ds_cur;
       float dy1[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
